@@ -1,0 +1,867 @@
+// libstitch_hip.so -- host side of the C ABI in include/stitch.h: argument checks, device workspace (plans),
+// launch sequencing on HIP streams, per-stage event timing.  All arithmetic is in stitch_kernels.hpp.
+// Built for gfx950 only (hipcc --offload-arch=gfx950 -ffp-contract=off); there is no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "stitch.h"
+#include "stitch_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace sk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) return fail(STITCH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                                   \
+    } while (0)
+
+int need_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(STITCH_ERR_NO_DEVICE, "no HIP device visible (hipGetDeviceCount: %s); this library has no CPU path",
+                    e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    }
+    return STITCH_OK;
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+constexpr double kPI = 3.14159265358979323846;  // cimg::PI
+
+// Projection.cpp:24-28: flag, width/height swap, tanVal rounded to float, r = (width/2.0)/tanVal stored to float
+struct ProjParams {
+    int flag, width, height;
+    float r;
+};
+ProjParams proj_params(int w, int h, float fov_deg) {
+    ProjParams p;
+    p.flag = w > h;
+    p.width = p.flag ? h : w;
+    p.height = p.flag ? w : h;
+    const float tanVal = (float)std::tan((double)fov_deg * kPI / 180.0);
+    p.r = (float)((p.width / 2.0) / tanVal);
+    return p;
+}
+
+// CImg.h:35053-35065 + :34889-34903
+VVK make_vvk(float sigma) {
+    const float nsigma = sigma >= 0 ? sigma : -sigma;
+    const double nnsigma = nsigma < 0.5f ? 0.5f : nsigma, m0 = 1.16680, m1 = 1.10783, m2 = 1.40586, m1sq = m1 * m1,
+                 m2sq = m2 * m2,
+                 q = (nnsigma < 3.556 ? -0.2568 + 0.5784 * nnsigma + 0.0561 * nnsigma * nnsigma
+                                      : 2.5091 + 0.9804 * (nnsigma - 3.556)),
+                 qsq = q * q, scale = (m0 + q) * (m1sq + m2sq + 2 * m1 * q + qsq),
+                 b1 = -q * (2 * m0 * m1 + m1sq + m2sq + (2 * m0 + 4 * m1) * q + 3 * qsq) / scale,
+                 b2 = qsq * (m0 + 2 * m1 + 3 * q) / scale, b3 = -qsq * q / scale, B = (m0 * (m1sq + m2sq)) / scale;
+    const double sumsq = B, sum = sumsq * sumsq, a1 = -b1, a2 = -b2, a3 = -b3,
+                 scaleM = 1.0 / ((1.0 + a1 - a2 + a3) * (1.0 - a1 - a2 - a3) * (1.0 + a2 + (a1 - a3) * a3));
+    VVK k;
+    k.f1 = a1;
+    k.f2 = a2;
+    k.f3 = a3;
+    k.sumsq = sumsq;
+    k.sum = sum;
+    k.den = 1.0 - a1 - a2 - a3;
+    k.M[0] = scaleM * (-a3 * a1 + 1.0 - a3 * a3 - a2);
+    k.M[1] = scaleM * (a3 + a1) * (a2 + a3 * a1);
+    k.M[2] = scaleM * a3 * (a1 + a3 * a2);
+    k.M[3] = scaleM * (a1 + a3 * a2);
+    k.M[4] = -scaleM * (a2 - 1.0) * (a2 + a3 * a1);
+    k.M[5] = -scaleM * a3 * (a3 * a1 + a3 * a3 + a2 - 1.0);
+    k.M[6] = scaleM * (a3 * a1 + a2 + a1 * a1 - a2 * a2);
+    k.M[7] = scaleM * (a1 * a2 + a3 * a2 * a2 - a1 * a3 * a3 - a3 * a3 * a3 - a3 * a2 + a3);
+    k.M[8] = scaleM * a3 * (a1 + a3 * a2);
+    return k;
+}
+
+// CImg.h:34801-34816,34840-34841 (float throughout; std::exp(float) is the float overload)
+DRK make_drk(float sigma) {
+    const float nsigma = sigma >= 0 ? sigma : -sigma;
+    const float nnsigma = nsigma < 0.1f ? 0.1f : nsigma, alpha = 1.695f / nnsigma, ema = std::exp(-alpha),
+                ema2 = std::exp(-2 * alpha), b1 = -2 * ema, b2 = ema2;
+    const float kk = (1 - ema) * (1 - ema) / (1 + 2 * alpha * ema - ema2);
+    DRK k;
+    k.a0 = kk;
+    k.a1 = kk * (alpha - 1) * ema;
+    k.a2 = kk * (alpha + 1) * ema;
+    k.a3 = -kk * ema2;
+    k.b1 = b1;
+    k.b2 = b2;
+    k.coefp = (k.a0 + k.a1) / (1 + b1 + b2);
+    k.coefn = (k.a2 + k.a3) / (1 + b1 + b2);
+    return k;
+}
+
+// CImg.h:29625-29637: idx/alpha of the linear up-sampling walk
+void expand_table(int n_src, int n_dst, std::vector<int32_t>& idx, std::vector<double>& alpha) {
+    idx.resize(n_dst);
+    alpha.resize(n_dst);
+    if (n_src == 1) {
+        for (int x = 0; x < n_dst; ++x) idx[x] = 0, alpha[x] = 0;
+        return;
+    }
+    const double fx = n_dst > 1 ? (n_src - 1.0) / (n_dst - 1) : 0;
+    double curr = 0;
+    for (int x = 0; x < n_dst; ++x) {
+        idx[x] = (int32_t)(unsigned int)curr;
+        alpha[x] = curr - (unsigned int)curr;
+        const double nxt = curr + fx;
+        curr = (n_src - 1.0) < nxt ? (n_src - 1.0) : nxt;
+    }
+}
+
+int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
+    if (w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "pyramid: non-positive size %dx%d", w, h);
+    const int len = level_rule ? (w < h ? w : h) : (w >= h ? w : h);
+    int levels = 0;
+    while ((len >> (levels + 1)) > 0) ++levels;  // floor(log2(len)), ImageProcess.cpp:675-676
+    if (levels < 1 || levels > 32) return fail(STITCH_ERR_PYRAMID, "pyramid: %dx%d gives %d levels", w, h, levels);
+    int cw = w, ch = h;
+    for (int i = 0; i < levels; ++i) {
+        if (cw <= 0 || ch <= 0)
+            return fail(STITCH_ERR_PYRAMID, "pyramid: level %d of %dx%d has a zero dimension (the reference degenerates here)",
+                        i, w, h);
+        if (lw) lw[i] = cw;
+        if (lh) lh[i] = ch;
+        cw /= 2;  // ImageProcess.cpp:706-707
+        ch /= 2;
+    }
+    return levels;
+}
+
+struct Level {
+    int w, h, pitch;
+    size_t ps;       // plane stride in floats = pitch*h
+    float* g;        // 7 planes [a0 a1 a2 b0 b1 b2 m] + 64 slack rows
+    float* e;        // 3 planes (collapse chain), levels >= 1
+    int32_t *ix, *iy;  // expand tables level+1 -> level (levels < L-1)
+    double *ax, *ay;
+};
+
+struct ProfRec {
+    int stage, level;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct stitch_plan {
+    int device = 0;
+    int cw = 0, ch = 0, L = 0;
+    stitch_blend_opts opts{};
+    Level lv[32]{};
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    float* T = nullptr;   // blur scratch, 7 planes of level 0 + slack
+    float* T2 = nullptr;  // Deriche temporaries (blur_kind 1 only)
+    double* state = nullptr;
+    SeamDev* d_seam = nullptr;
+    SeamDev* h_seam = nullptr;  // pinned
+    hipStream_t last_stream = nullptr;
+    bool pending = false;
+    VVK vvk{};
+    DRK drk{};
+    bool blur_skip = false;
+    bool profiling = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> free_events;
+};
+
+namespace {
+
+struct StageTimer {  // records a pair of events around a group of launches when profiling is on
+    stitch_plan* p;
+    hipStream_t s;
+    ProfRec r{};
+    bool on;
+    StageTimer(stitch_plan* plan, hipStream_t st, int stage, int level) : p(plan), s(st), on(plan->profiling) {
+        if (!on) return;
+        r.stage = stage;
+        r.level = level;
+        auto get = [&](hipEvent_t& e) {
+            if (!p->free_events.empty()) {
+                e = p->free_events.back();
+                p->free_events.pop_back();
+            } else
+                (void)hipEventCreate(&e);
+        };
+        get(r.a);
+        get(r.b);
+        (void)hipEventRecord(r.a, s);
+    }
+    ~StageTimer() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        p->recs.push_back(r);
+    }
+};
+
+dim3 grid_xy(int pitch_or_w, int h, int z = 1) { return dim3((pitch_or_w + 255) / 256, h, z); }
+
+int launch_check(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(STITCH_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return STITCH_OK;
+}
+
+// REDUCE for every level (ImageProcess.cpp:705-715): blur(G_l) into T, decimate T into G_{l+1}.
+int run_reduce(stitch_plan* p, hipStream_t s) {
+    for (int l = 0; l + 1 < p->L; ++l) {
+        const Level& a = p->lv[l];
+        const Level& b = p->lv[l + 1];
+        const long lines = 7L * a.h;
+        const bool do_x = a.w > 1 && !p->blur_skip, do_y = a.h > 1 && !p->blur_skip;
+        if (p->opts.blur_kind == 0) {
+            {
+                StageTimer t(p, s, STITCH_STAGE_BLUR_X, l);
+                if (do_x) {
+                    const int nb = (int)((lines + TS - 1) / TS);
+                    k_vv_x_fwd<<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state);
+                    k_vv_x_bwd<<<nb, 64, 0, s>>>(p->T, a.w, a.pitch, lines, p->vvk, p->state);
+                } else
+                    HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * 7, hipMemcpyDeviceToDevice, s));
+            }
+            if (do_y) {
+                StageTimer t(p, s, STITCH_STAGE_BLUR_Y, l);
+                dim3 g(a.pitch / 64, 7);
+                k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
+                k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
+            }
+        } else {
+            HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * 7, hipMemcpyDeviceToDevice, s));
+            if (do_x) {
+                StageTimer t(p, s, STITCH_STAGE_BLUR_X, l);
+                k_deriche<<<(int)((lines + 63) / 64), 64, 0, s>>>(p->T, p->T2, a.w, 1, a.pitch, a.h, a.ps, lines, p->drk);
+            }
+            if (do_y) {
+                StageTimer t(p, s, STITCH_STAGE_BLUR_Y, l);
+                const long cols = 7L * a.w;
+                k_deriche<<<(int)((cols + 63) / 64), 64, 0, s>>>(p->T, p->T2, a.h, a.pitch, 1, a.w, a.ps, cols, p->drk);
+            }
+        }
+        {
+            StageTimer t(p, s, STITCH_STAGE_DECIMATE, l);
+            k_decimate<<<grid_xy(b.pitch, b.h, 7), 256, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, b.g, b.w, b.h, b.pitch, b.ps);
+        }
+    }
+    return launch_check("reduce");
+}
+
+template <typename OUT>
+int run_collapse(stitch_plan* p, OUT* d_out, hipStream_t s) {
+    const int L = p->L;
+    {
+        const Level& t = p->lv[L - 1];
+        StageTimer tm(p, s, STITCH_STAGE_COLLAPSE, L - 1);
+        k_blend_top<<<grid_xy(t.pitch, t.h), 256, 0, s>>>(t.g, t.pitch, t.h, t.ps, t.e);
+        if (L == 1) k_emit_top<OUT><<<grid_xy(t.w, t.h), 256, 0, s>>>(t.e, t.w, t.h, t.pitch, t.ps, d_out);
+    }
+    for (int l = L - 2; l >= 0; --l) {
+        const Level& a = p->lv[l];
+        const Level& n = p->lv[l + 1];
+        StageTimer tm(p, s, STITCH_STAGE_COLLAPSE, l);
+        ExpandTab tb{a.ix, a.ax, a.iy, a.ay};
+        if (l == 0)
+            k_collapse<OUT, true><<<grid_xy(a.w, a.h), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, n.g, n.e, n.w, n.h, n.pitch,
+                                                                    n.ps, tb, d_out, a.w, (size_t)a.w * a.h);
+        else
+            k_collapse<float, false><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, n.g, n.e, n.w, n.h,
+                                                                           n.pitch, n.ps, tb, a.e, a.pitch, a.ps);
+    }
+    return launch_check("collapse");
+}
+
+int run_seam_mask(stitch_plan* p, hipStream_t s) {
+    const Level& a = p->lv[0];
+    k_seam<<<1, 1024, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam);
+    k_mask<<<grid_xy(a.pitch, a.h), 256, 0, s>>>(a.g + 6 * a.ps, a.w, a.pitch, p->d_seam);
+    HIPCHK(hipMemcpyAsync(p->h_seam, p->d_seam, sizeof(SeamDev), hipMemcpyDeviceToHost, s));
+    return launch_check("seam/mask");
+}
+
+int check_plan_call(stitch_plan* p, const void* a, const void* b, const void* out) {
+    if (!p || !a || !b || !out) return fail(STITCH_ERR_ARG, "null plan or buffer");
+    int dev = -1;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev != p->device) return fail(STITCH_ERR_ARG, "plan belongs to device %d, current device is %d", p->device, dev);
+    return STITCH_OK;
+}
+
+template <typename PX>
+int dev_blend(stitch_plan* p, const PX* d_a, const PX* d_b, PX* d_out, void* stream) {
+    int rc = check_plan_call(p, d_a, d_b, d_out);
+    if (rc) return rc;
+    hipStream_t s = as_stream(stream);
+    const Level& a = p->lv[0];
+    {
+        StageTimer t(p, s, STITCH_STAGE_COMPOSE, 0);
+        k_load_canvases<PX><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(d_a, d_b, a.g, a.w, a.h, a.pitch, a.ps);
+        if ((rc = run_seam_mask(p, s))) return rc;
+    }
+    if ((rc = run_reduce(p, s))) return rc;
+    if ((rc = run_collapse<PX>(p, d_out, s))) return rc;
+    p->last_stream = s;
+    p->pending = true;
+    return STITCH_OK;
+}
+
+template <typename PX>
+int dev_pair(stitch_plan* p, const PX* d_frame, int fw, int fh, const double pm[8], float offx, float offy,
+             const PX* d_mosaic, int mw, int mh, int ox, int oy, PX* d_out, void* stream) {
+    int rc = check_plan_call(p, d_frame, d_mosaic, d_out);
+    if (rc) return rc;
+    if (!pm || fw <= 0 || fh <= 0 || mw <= 0 || mh <= 0) return fail(STITCH_ERR_ARG, "pair: bad frame/mosaic size or null map");
+    hipStream_t s = as_stream(stream);
+    const Level& a = p->lv[0];
+    MapP m;
+    std::memcpy(m.p, pm, sizeof m.p);
+    {
+        StageTimer t(p, s, STITCH_STAGE_COMPOSE, 0);
+        k_compose<PX><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(d_frame, fw, fh, m, offx, offy, d_mosaic, mw, mh, ox, oy, a.g, a.w,
+                                                           a.h, a.pitch, a.ps);
+        if ((rc = run_seam_mask(p, s))) return rc;
+    }
+    if ((rc = run_reduce(p, s))) return rc;
+    if ((rc = run_collapse<PX>(p, d_out, s))) return rc;
+    p->last_stream = s;
+    p->pending = true;
+    return STITCH_OK;
+}
+
+void seam_to_public(const SeamDev& d, stitch_seam* o) {
+    if (!o) return;
+    o->sum_a_x = d.sum_a_x;
+    o->n_a = d.n_a;
+    o->sum_ov_x = d.sum_ov_x;
+    o->n_ov = d.n_ov;
+    o->ratio = d.ratio;
+    o->ov = d.ov;
+    o->branch = d.branch;
+    o->start = d.start;
+}
+
+template <typename PX>
+int dev_project(const PX* d_src, int w, int h, float fov_deg, PX* d_dst, void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_src || !d_dst || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "project: null buffer or bad size %dx%d", w, h);
+    const ProjParams pp = proj_params(w, h, fov_deg);
+    k_project<PX><<<grid_xy(w, h), 256, 0, as_stream(stream)>>>(d_src, d_dst, w, h, pp.flag, pp.width, pp.height, pp.r);
+    return launch_check("k_project");
+}
+
+template <typename PX>
+int dev_warp(const PX* d_src, int sw, int sh, const double pm[8], float offx, float offy, PX* d_canvas, int cw, int ch,
+             void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_src || !d_canvas || !pm || sw <= 0 || sh <= 0 || cw <= 0 || ch <= 0) return fail(STITCH_ERR_ARG, "warp: bad argument");
+    MapP m;
+    std::memcpy(m.p, pm, sizeof m.p);
+    k_warp<PX><<<grid_xy(cw, ch), 256, 0, as_stream(stream)>>>(d_src, sw, sh, m, offx, offy, d_canvas, cw, ch);
+    return launch_check("k_warp");
+}
+
+template <typename PX>
+int dev_move(const PX* d_src, int sw, int sh, int ox, int oy, PX* d_canvas, int cw, int ch, void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_src || !d_canvas || sw <= 0 || sh <= 0 || cw <= 0 || ch <= 0) return fail(STITCH_ERR_ARG, "move: bad argument");
+    k_move<PX><<<grid_xy(cw, ch), 256, 0, as_stream(stream)>>>(d_src, sw, sh, ox, oy, d_canvas, cw, ch);
+    return launch_check("k_move");
+}
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        HIPCHK(hipMalloc(&p, bytes));
+        return STITCH_OK;
+    }
+    template <typename T>
+    T* as() {
+        return static_cast<T*>(p);
+    }
+};
+
+template <typename PX>
+int host_project(const PX* src, int w, int h, float fov_deg, PX* dst) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!src || !dst || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "project: null buffer or bad size %dx%d", w, h);
+    const size_t bytes = sizeof(PX) * (size_t)w * h * 3;
+    DevBuf s, d;
+    if ((rc = s.alloc(bytes)) || (rc = d.alloc(bytes))) return rc;
+    HIPCHK(hipMemcpy(s.p, src, bytes, hipMemcpyHostToDevice));
+    if ((rc = dev_project<PX>(s.as<PX>(), w, h, fov_deg, d.as<PX>(), nullptr))) return rc;
+    HIPCHK(hipMemcpy(dst, d.p, bytes, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+
+template <typename PX>
+int host_warp(const PX* src, int sw, int sh, const double pm[8], float offx, float offy, PX* canvas, int cw, int ch) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!src || !canvas || !pm || sw <= 0 || sh <= 0 || cw <= 0 || ch <= 0) return fail(STITCH_ERR_ARG, "warp: bad argument");
+    const size_t sb = sizeof(PX) * (size_t)sw * sh * 3, cb = sizeof(PX) * (size_t)cw * ch * 3;
+    DevBuf s, c;
+    if ((rc = s.alloc(sb)) || (rc = c.alloc(cb))) return rc;
+    HIPCHK(hipMemcpy(s.p, src, sb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c.p, canvas, cb, hipMemcpyHostToDevice));
+    if ((rc = dev_warp<PX>(s.as<PX>(), sw, sh, pm, offx, offy, c.as<PX>(), cw, ch, nullptr))) return rc;
+    HIPCHK(hipMemcpy(canvas, c.p, cb, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+
+template <typename PX>
+int host_move(const PX* src, int sw, int sh, int ox, int oy, PX* canvas, int cw, int ch) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!src || !canvas || sw <= 0 || sh <= 0 || cw <= 0 || ch <= 0) return fail(STITCH_ERR_ARG, "move: bad argument");
+    const size_t sb = sizeof(PX) * (size_t)sw * sh * 3, cb = sizeof(PX) * (size_t)cw * ch * 3;
+    DevBuf s, c;
+    if ((rc = s.alloc(sb)) || (rc = c.alloc(cb))) return rc;
+    HIPCHK(hipMemcpy(s.p, src, sb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c.p, canvas, cb, hipMemcpyHostToDevice));
+    if ((rc = dev_move<PX>(s.as<PX>(), sw, sh, ox, oy, c.as<PX>(), cw, ch, nullptr))) return rc;
+    HIPCHK(hipMemcpy(canvas, c.p, cb, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+
+struct PlanGuard {
+    stitch_plan* p = nullptr;
+    ~PlanGuard() { stitch_plan_destroy(p); }
+};
+
+template <typename PX>
+int host_blend(const PX* a, const PX* b, int w, int h, const stitch_blend_opts* opts, PX* out, stitch_seam* seam_out) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!a || !b || !out || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "blend: null buffer or bad size %dx%d", w, h);
+    PlanGuard pg;
+    if ((rc = stitch_plan_create(w, h, opts, &pg.p))) return rc;
+    const size_t bytes = sizeof(PX) * (size_t)w * h * 3;
+    DevBuf da, db, dout;
+    if ((rc = da.alloc(bytes)) || (rc = db.alloc(bytes)) || (rc = dout.alloc(bytes))) return rc;
+    HIPCHK(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    if ((rc = dev_blend<PX>(pg.p, da.as<PX>(), db.as<PX>(), dout.as<PX>(), nullptr))) return rc;
+    if ((rc = stitch_plan_status(pg.p, seam_out))) return rc;
+    HIPCHK(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+
+template <typename PX>
+int host_pair(const PX* frame, int fw, int fh, const double pm[8], float offx, float offy, const PX* mosaic, int mw, int mh,
+              int ox, int oy, int cw, int ch, const stitch_blend_opts* opts, PX* out, stitch_seam* seam_out) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!frame || !mosaic || !out || !pm || fw <= 0 || fh <= 0 || mw <= 0 || mh <= 0 || cw <= 0 || ch <= 0)
+        return fail(STITCH_ERR_ARG, "pair: bad argument");
+    PlanGuard pg;
+    if ((rc = stitch_plan_create(cw, ch, opts, &pg.p))) return rc;
+    const size_t fb = sizeof(PX) * (size_t)fw * fh * 3, mb = sizeof(PX) * (size_t)mw * mh * 3,
+                 ob = sizeof(PX) * (size_t)cw * ch * 3;
+    DevBuf df, dm, dout;
+    if ((rc = df.alloc(fb)) || (rc = dm.alloc(mb)) || (rc = dout.alloc(ob))) return rc;
+    HIPCHK(hipMemcpy(df.p, frame, fb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dm.p, mosaic, mb, hipMemcpyHostToDevice));
+    if ((rc = dev_pair<PX>(pg.p, df.as<PX>(), fw, fh, pm, offx, offy, dm.as<PX>(), mw, mh, ox, oy, dout.as<PX>(), nullptr)))
+        return rc;
+    if ((rc = stitch_plan_status(pg.p, seam_out))) return rc;
+    HIPCHK(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+
+int eq_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (int)(g < 2048 ? (g ? g : 1) : 2048);  // memory-bound: cap the grid and stride (guide 6, guideline 11)
+}
+
+// E1-E3 (+ optional fused M1).  Scratch (256-bin histogram + LUT) comes from the stream-ordered allocator, so
+// concurrent calls on different streams do not share state.
+int dev_equalize_impl(uint8_t* d_img, int w, int h, int32_t* d_hist_out, bool fuse_mix, double num, double den, void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_img || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "equalize: null buffer or bad size %dx%d", w, h);
+    if ((long long)w * h > 0x7fffffffLL) return fail(STITCH_ERR_ARG, "equalize: w*h overflows int (the reference's int product)");
+    hipStream_t s = as_stream(stream);
+    int32_t* scratch = nullptr;
+    HIPCHK(hipMallocAsync((void**)&scratch, sizeof(int32_t) * 512, s));
+    int32_t *hist = scratch, *lut = scratch + 256;
+    HIPCHK(hipMemsetAsync(hist, 0, sizeof(int32_t) * 256, s));
+    const size_t n = (size_t)w * h;
+    k_hist<<<eq_grid(n), HIST_WAVES * 64, 0, s>>>(d_img, n, hist);
+    k_lut<<<1, 64, 0, s>>>(hist, w, h, lut);
+    if (fuse_mix)
+        k_equalize_apply<true><<<eq_grid(n), 256, 0, s>>>(d_img, n, lut, num, den);
+    else
+        k_equalize_apply<false><<<eq_grid(n), 256, 0, s>>>(d_img, n, lut, 0.0, 1.0);
+    if (d_hist_out) HIPCHK(hipMemcpyAsync(d_hist_out, hist, sizeof(int32_t) * 256, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipFreeAsync(scratch, s));
+    return launch_check("equalize");
+}
+
+}  // namespace
+
+// =========================================== C ABI ==========================================================
+extern "C" {
+
+int stitch_abi_version(void) { return STITCH_ABI_VERSION; }
+const char* stitch_last_error(void) { return g_err.c_str(); }
+
+int stitch_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int stitch_set_device(int ordinal) {
+    int rc = need_device();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ordinal));
+    return STITCH_OK;
+}
+
+void stitch_blend_opts_default(stitch_blend_opts* o) {
+    if (!o) return;
+    o->sigma = 2.0f;
+    o->blur_kind = 0;
+    o->level_rule = 0;
+    o->seam_rule = 0;
+}
+
+int stitch_pyramid_levels(int w, int h, int level_rule, int* level_w, int* level_h) {
+    return pyramid_levels(w, h, level_rule, level_w, level_h);
+}
+
+int stitch_project_u8(const uint8_t* src, int w, int h, float fov_deg, uint8_t* dst) { return host_project(src, w, h, fov_deg, dst); }
+int stitch_project_f32(const float* src, int w, int h, float fov_deg, float* dst) { return host_project(src, w, h, fov_deg, dst); }
+int stitch_warp_u8(const uint8_t* src, int sw, int sh, const double p[8], float offx, float offy, uint8_t* canvas, int cw, int ch) {
+    return host_warp(src, sw, sh, p, offx, offy, canvas, cw, ch);
+}
+int stitch_warp_f32(const float* src, int sw, int sh, const double p[8], float offx, float offy, float* canvas, int cw, int ch) {
+    return host_warp(src, sw, sh, p, offx, offy, canvas, cw, ch);
+}
+int stitch_move_u8(const uint8_t* src, int sw, int sh, int ox, int oy, uint8_t* canvas, int cw, int ch) {
+    return host_move(src, sw, sh, ox, oy, canvas, cw, ch);
+}
+int stitch_move_f32(const float* src, int sw, int sh, int ox, int oy, float* canvas, int cw, int ch) {
+    return host_move(src, sw, sh, ox, oy, canvas, cw, ch);
+}
+int stitch_blend_u8(const uint8_t* a, const uint8_t* b, int w, int h, const stitch_blend_opts* opts, uint8_t* out,
+                    stitch_seam* seam_out) {
+    return host_blend(a, b, w, h, opts, out, seam_out);
+}
+int stitch_blend_f32(const float* a, const float* b, int w, int h, const stitch_blend_opts* opts, float* out, stitch_seam* seam_out) {
+    return host_blend(a, b, w, h, opts, out, seam_out);
+}
+int stitch_pair_u8(const uint8_t* frame, int fw, int fh, const double p[8], float offx, float offy, const uint8_t* mosaic, int mw,
+                   int mh, int ox, int oy, int cw, int ch, const stitch_blend_opts* opts, uint8_t* out, stitch_seam* seam_out) {
+    return host_pair(frame, fw, fh, p, offx, offy, mosaic, mw, mh, ox, oy, cw, ch, opts, out, seam_out);
+}
+int stitch_pair_f32(const float* frame, int fw, int fh, const double p[8], float offx, float offy, const float* mosaic, int mw,
+                    int mh, int ox, int oy, int cw, int ch, const stitch_blend_opts* opts, float* out, stitch_seam* seam_out) {
+    return host_pair(frame, fw, fh, p, offx, offy, mosaic, mw, mh, ox, oy, cw, ch, opts, out, seam_out);
+}
+
+int stitch_equalize_u8(uint8_t* img, int w, int h, int32_t hist_out[256]) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!img || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "equalize: null buffer or bad size %dx%d", w, h);
+    const size_t bytes = (size_t)w * h * 3;
+    DevBuf d, dh;
+    if ((rc = d.alloc(bytes)) || (rc = dh.alloc(sizeof(int32_t) * 256))) return rc;
+    HIPCHK(hipMemcpy(d.p, img, bytes, hipMemcpyHostToDevice));
+    if ((rc = dev_equalize_impl(d.as<uint8_t>(), w, h, dh.as<int32_t>(), false, 0, 1, nullptr))) return rc;
+    HIPCHK(hipMemcpy(img, d.p, bytes, hipMemcpyDeviceToHost));
+    if (hist_out) HIPCHK(hipMemcpy(hist_out, dh.p, sizeof(int32_t) * 256, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+
+int stitch_lummix_u8(uint8_t* result, const uint8_t* equalized, int w, int h, double num, double den) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!result || !equalized || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "lummix: null buffer or bad size %dx%d", w, h);
+    const size_t bytes = (size_t)w * h * 3;
+    DevBuf r, e;
+    if ((rc = r.alloc(bytes)) || (rc = e.alloc(bytes))) return rc;
+    HIPCHK(hipMemcpy(r.p, result, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e.p, equalized, bytes, hipMemcpyHostToDevice));
+    if ((rc = stitch_dev_lummix_u8(r.as<uint8_t>(), e.as<uint8_t>(), w, h, num, den, nullptr))) return rc;
+    HIPCHK(hipMemcpy(result, r.p, bytes, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+
+int stitch_finish_u8(uint8_t* result, int w, int h, double num, double den, int32_t hist_out[256]) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!result || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "finish: null buffer or bad size %dx%d", w, h);
+    const size_t bytes = (size_t)w * h * 3;
+    DevBuf d, dh;
+    if ((rc = d.alloc(bytes)) || (rc = dh.alloc(sizeof(int32_t) * 256))) return rc;
+    HIPCHK(hipMemcpy(d.p, result, bytes, hipMemcpyHostToDevice));
+    if ((rc = dev_equalize_impl(d.as<uint8_t>(), w, h, dh.as<int32_t>(), true, num, den, nullptr))) return rc;
+    HIPCHK(hipMemcpy(result, d.p, bytes, hipMemcpyDeviceToHost));
+    if (hist_out) HIPCHK(hipMemcpy(hist_out, dh.p, sizeof(int32_t) * 256, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+
+int stitch_dev_project_u8(const uint8_t* d_src, int w, int h, float fov_deg, uint8_t* d_dst, void* stream) {
+    return dev_project(d_src, w, h, fov_deg, d_dst, stream);
+}
+int stitch_dev_project_f32(const float* d_src, int w, int h, float fov_deg, float* d_dst, void* stream) {
+    return dev_project(d_src, w, h, fov_deg, d_dst, stream);
+}
+int stitch_dev_warp_u8(const uint8_t* d_src, int sw, int sh, const double p[8], float offx, float offy, uint8_t* d_canvas, int cw,
+                       int ch, void* stream) {
+    return dev_warp(d_src, sw, sh, p, offx, offy, d_canvas, cw, ch, stream);
+}
+int stitch_dev_warp_f32(const float* d_src, int sw, int sh, const double p[8], float offx, float offy, float* d_canvas, int cw,
+                        int ch, void* stream) {
+    return dev_warp(d_src, sw, sh, p, offx, offy, d_canvas, cw, ch, stream);
+}
+int stitch_dev_move_u8(const uint8_t* d_src, int sw, int sh, int ox, int oy, uint8_t* d_canvas, int cw, int ch, void* stream) {
+    return dev_move(d_src, sw, sh, ox, oy, d_canvas, cw, ch, stream);
+}
+int stitch_dev_move_f32(const float* d_src, int sw, int sh, int ox, int oy, float* d_canvas, int cw, int ch, void* stream) {
+    return dev_move(d_src, sw, sh, ox, oy, d_canvas, cw, ch, stream);
+}
+
+int stitch_plan_create(int cw, int ch, const stitch_blend_opts* opts, stitch_plan** plan_out) {
+    if (!plan_out) return fail(STITCH_ERR_ARG, "plan_create: null plan_out");
+    *plan_out = nullptr;
+    int rc = need_device();
+    if (rc) return rc;
+    stitch_blend_opts o;
+    stitch_blend_opts_default(&o);
+    if (opts) o = *opts;
+    if (o.blur_kind < 0 || o.blur_kind > 1 || o.level_rule < 0 || o.level_rule > 1 || o.seam_rule < 0 || o.seam_rule > 1 ||
+        !(o.sigma >= 0))
+        return fail(STITCH_ERR_ARG, "plan_create: bad blend options");
+    int lw[32], lh[32];
+    const int L = pyramid_levels(cw, ch, o.level_rule, lw, lh);
+    if (L < 0) return L;
+
+    stitch_plan* p = new stitch_plan();
+    p->cw = cw;
+    p->ch = ch;
+    p->L = L;
+    p->opts = o;
+    p->vvk = make_vvk(o.sigma);
+    p->drk = make_drk(o.sigma);
+    p->blur_skip = o.blur_kind == 0 ? (o.sigma < 0.5f) : (o.sigma < 0.1f);  // CImg.h:35051 / :34800
+    if (hipGetDevice(&p->device) != hipSuccess) {
+        delete p;
+        return fail(STITCH_ERR_HIP, "hipGetDevice failed");
+    }
+    // carve one arena
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o2 = off;
+        off += align256(bytes);
+        return o2;
+    };
+    size_t g_off[32], e_off[32], ix_off[32], ax_off[32], iy_off[32], ay_off[32];
+    for (int l = 0; l < L; ++l) {
+        Level& v = p->lv[l];
+        v.w = lw[l];
+        v.h = lh[l];
+        v.pitch = round_up(v.w, 64);
+        v.ps = (size_t)v.pitch * v.h;
+        g_off[l] = take(sizeof(float) * (v.ps * 7 + (size_t)v.pitch * 64));
+        e_off[l] = l >= 1 || L == 1 ? take(sizeof(float) * v.ps * 3) : 0;
+        if (l + 1 < L) {
+            ix_off[l] = take(sizeof(int32_t) * v.w);
+            ax_off[l] = take(sizeof(double) * v.w);
+            iy_off[l] = take(sizeof(int32_t) * v.h);
+            ay_off[l] = take(sizeof(double) * v.h);
+        }
+    }
+    const Level& v0 = p->lv[0];
+    const size_t t_bytes = sizeof(float) * (v0.ps * 7 + (size_t)v0.pitch * 64);
+    const size_t t_off = take(t_bytes);
+    const size_t t2_off = o.blur_kind == 1 ? take(t_bytes) : 0;
+    const size_t state_n = 4 * 7 * (size_t)std::max(v0.h + 64, v0.pitch);
+    const size_t st_off = take(sizeof(double) * state_n);
+    const size_t seam_off = take(sizeof(SeamDev));
+    p->arena_bytes = off;
+    if (hipMalloc(&p->arena, off) != hipSuccess) {
+        (void)hipGetLastError();
+        delete p;
+        return fail(STITCH_ERR_HIP, "plan_create: hipMalloc of %zu bytes failed", off);
+    }
+    char* base = static_cast<char*>(p->arena);
+    for (int l = 0; l < L; ++l) {
+        Level& v = p->lv[l];
+        v.g = reinterpret_cast<float*>(base + g_off[l]);
+        v.e = (l >= 1 || L == 1) ? reinterpret_cast<float*>(base + e_off[l]) : nullptr;
+        if (l + 1 < L) {
+            v.ix = reinterpret_cast<int32_t*>(base + ix_off[l]);
+            v.ax = reinterpret_cast<double*>(base + ax_off[l]);
+            v.iy = reinterpret_cast<int32_t*>(base + iy_off[l]);
+            v.ay = reinterpret_cast<double*>(base + ay_off[l]);
+        }
+    }
+    p->T = reinterpret_cast<float*>(base + t_off);
+    p->T2 = o.blur_kind == 1 ? reinterpret_cast<float*>(base + t2_off) : nullptr;
+    p->state = reinterpret_cast<double*>(base + st_off);
+    p->d_seam = reinterpret_cast<SeamDev*>(base + seam_off);
+    // the slack rows and pitch padding are read by partial tiles: give them defined (zero) contents once
+    if (hipMemset(p->arena, 0, off) != hipSuccess || hipHostMalloc((void**)&p->h_seam, sizeof(SeamDev)) != hipSuccess) {
+        stitch_plan_destroy(p);
+        return fail(STITCH_ERR_HIP, "plan_create: workspace initialisation failed");
+    }
+    // resize tables (CImg.h:29625-29637), computed on the host once per plan
+    for (int l = 0; l + 1 < L; ++l) {
+        Level& v = p->lv[l];
+        std::vector<int32_t> idx;
+        std::vector<double> al;
+        expand_table(lw[l + 1], v.w, idx, al);
+        (void)hipMemcpy(v.ix, idx.data(), sizeof(int32_t) * v.w, hipMemcpyHostToDevice);
+        (void)hipMemcpy(v.ax, al.data(), sizeof(double) * v.w, hipMemcpyHostToDevice);
+        expand_table(lh[l + 1], v.h, idx, al);
+        (void)hipMemcpy(v.iy, idx.data(), sizeof(int32_t) * v.h, hipMemcpyHostToDevice);
+        if (hipMemcpy(v.ay, al.data(), sizeof(double) * v.h, hipMemcpyHostToDevice) != hipSuccess) {
+            stitch_plan_destroy(p);
+            return fail(STITCH_ERR_HIP, "plan_create: table upload failed");
+        }
+    }
+    std::memset(p->h_seam, 0, sizeof(SeamDev));
+    *plan_out = p;
+    return STITCH_OK;
+}
+
+void stitch_plan_destroy(stitch_plan* p) {
+    if (!p) return;
+    if (p->pending && p->last_stream != nullptr) (void)hipStreamSynchronize(p->last_stream);
+    else if (p->pending) (void)hipDeviceSynchronize();
+    for (auto& r : p->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : p->free_events) (void)hipEventDestroy(e);
+    if (p->arena) (void)hipFree(p->arena);
+    if (p->h_seam) (void)hipHostFree(p->h_seam);
+    delete p;
+}
+
+size_t stitch_plan_workspace_bytes(const stitch_plan* p) { return p ? p->arena_bytes : 0; }
+
+int stitch_plan_levels(const stitch_plan* p, int* level_w, int* level_h) {
+    if (!p) return fail(STITCH_ERR_ARG, "null plan");
+    for (int l = 0; l < p->L; ++l) {
+        if (level_w) level_w[l] = p->lv[l].w;
+        if (level_h) level_h[l] = p->lv[l].h;
+    }
+    return p->L;
+}
+
+int stitch_dev_blend_u8(stitch_plan* plan, const uint8_t* d_a, const uint8_t* d_b, uint8_t* d_out, void* stream) {
+    return dev_blend(plan, d_a, d_b, d_out, stream);
+}
+int stitch_dev_blend_f32(stitch_plan* plan, const float* d_a, const float* d_b, float* d_out, void* stream) {
+    return dev_blend(plan, d_a, d_b, d_out, stream);
+}
+int stitch_dev_pair_u8(stitch_plan* plan, const uint8_t* d_frame, int fw, int fh, const double p[8], float offx, float offy,
+                       const uint8_t* d_mosaic, int mw, int mh, int ox, int oy, uint8_t* d_out, void* stream) {
+    return dev_pair(plan, d_frame, fw, fh, p, offx, offy, d_mosaic, mw, mh, ox, oy, d_out, stream);
+}
+int stitch_dev_pair_f32(stitch_plan* plan, const float* d_frame, int fw, int fh, const double p[8], float offx, float offy,
+                        const float* d_mosaic, int mw, int mh, int ox, int oy, float* d_out, void* stream) {
+    return dev_pair(plan, d_frame, fw, fh, p, offx, offy, d_mosaic, mw, mh, ox, oy, d_out, stream);
+}
+
+int stitch_plan_status(stitch_plan* p, stitch_seam* seam_out) {
+    if (!p) return fail(STITCH_ERR_ARG, "null plan");
+    if (p->pending) {
+        HIPCHK(hipStreamSynchronize(p->last_stream));
+        p->pending = false;
+    }
+    seam_to_public(*p->h_seam, seam_out);
+    if (p->h_seam->status == -2) return fail(STITCH_ERR_EMPTY_MIDROW, "blend: channel 0 of a's middle row is empty");
+    if (p->h_seam->status == -3) return fail(STITCH_ERR_ZERO_OVERLAP, "blend: a and b do not overlap on the middle row");
+    return STITCH_OK;
+}
+
+int stitch_plan_set_profiling(stitch_plan* p, int enabled) {
+    if (!p) return fail(STITCH_ERR_ARG, "null plan");
+    p->profiling = enabled != 0;
+    return STITCH_OK;
+}
+
+int stitch_plan_read_profile(stitch_plan* p, double stage_ms[STITCH_STAGE_COUNT], int stage_launches[STITCH_STAGE_COUNT],
+                             double level0_ms[STITCH_STAGE_COUNT]) {
+    if (!p) return fail(STITCH_ERR_ARG, "null plan");
+    if (p->pending) {
+        HIPCHK(hipStreamSynchronize(p->last_stream));
+        p->pending = false;
+    }
+    for (int i = 0; i < STITCH_STAGE_COUNT; ++i) {
+        if (stage_ms) stage_ms[i] = 0;
+        if (stage_launches) stage_launches[i] = 0;
+        if (level0_ms) level0_ms[i] = 0;
+    }
+    for (auto& r : p->recs) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        if (stage_ms) stage_ms[r.stage] += ms;
+        if (stage_launches) stage_launches[r.stage] += 1;
+        if (level0_ms && r.level == 0) level0_ms[r.stage] += ms;
+        p->free_events.push_back(r.a);
+        p->free_events.push_back(r.b);
+    }
+    p->recs.clear();
+    return STITCH_OK;
+}
+
+int stitch_dev_equalize_u8(uint8_t* d_img, int w, int h, int32_t* d_hist256, void* stream) {
+    return dev_equalize_impl(d_img, w, h, d_hist256, false, 0, 1, stream);
+}
+
+int stitch_dev_lummix_u8(uint8_t* d_result, const uint8_t* d_equalized, int w, int h, double num, double den, void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_result || !d_equalized || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "lummix: null buffer or bad size %dx%d", w, h);
+    const size_t n = (size_t)w * h;
+    k_lummix<<<eq_grid(n), 256, 0, as_stream(stream)>>>(d_result, d_equalized, n, num, den);
+    return launch_check("k_lummix");
+}
+
+int stitch_dev_finish_u8(uint8_t* d_result, int w, int h, double num, double den, int32_t* d_hist256, void* stream) {
+    return dev_equalize_impl(d_result, w, h, d_hist256, true, num, den, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,832 @@
+// Hand-written gfx950 (CDNA4) kernels of the stitching hot path.  Included only by stitch_hip.hip.
+//
+// Numerics contract: the reference semantics are x86-64 SSE2 -- IEEE, strict left to right,
+// no FMA -- with the C++ promotions exactly as the reference writes them.  This translation unit is compiled
+// with -ffp-contract=off (and the pragma below), float and double divide / sqrt are the correctly rounded
+// forms, and every transcendental (tan, exp) is evaluated on the host and passed in.  Operation order inside
+// each function follows the cited reference lines; what is free is the mapping of samples to work-items.
+//
+// Layout: the blend's planes live in a pitched layout -- row pitch = width rounded up to 64 floats (256 B),
+// so every row starts on a 256-byte boundary and any 64-column tile can be moved with 16-byte-per-lane
+// accesses without bounds tests.  User-facing frames and canvases stay dense CImg planar buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace sk {
+
+constexpr int WAVE = 64;
+typedef float f4 __attribute__((ext_vector_type(4)));  // native 16-byte vector (keeps prefetch arrays in VGPRs)
+
+struct MapP {  // bilinear-map parameters, ImageProcess.h:58-73 order
+    double p[8];
+};
+
+struct VVK {  // Van Vliet constants, CImg.h:34889-34903 / :35053-35065 (computed on the host)
+    double f1, f2, f3, sumsq, sum, den;
+    double M[9];
+};
+
+struct DRK {  // Deriche constants, CImg.h:34801-34816,34840-34841 (all float)
+    float a0, a1, a2, a3, b1, b2, coefp, coefn;
+};
+
+struct SeamDev {  // written by k_seam, read by k_mask / the host
+    int32_t sum_a_x, n_a, sum_ov_x, n_ov;
+    float ratio, ov;
+    int32_t branch, start;
+    double thr;      // branch 0: mask = 1 where (double)x < thr
+    int32_t status;  // 0 ok, -2 empty mid row, -3 zero overlap
+    int32_t pad;
+};
+
+// ---- pixel helpers ---------------------------------------------------------------------------------------
+template <typename PX>
+__device__ __forceinline__ PX px_store(float f);
+template <>
+__device__ __forceinline__ uint8_t px_store<uint8_t>(float f) {
+    return (uint8_t)(int)f;  // C-cast truncation (values are in [0,256))
+}
+template <>
+__device__ __forceinline__ float px_store<float>(float f) {
+    return f;
+}
+
+// Projection::bilinearInterpolation, Projection.cpp:3-18: ((1-a)(1-b))*ld + (a(1-b))*rd + (ab)*rt + ((1-a)b)*lt,
+// summed left to right in float.  All three channels share the weights (the reference recomputes them per channel).
+template <typename PX>
+__device__ __forceinline__ void bilinear3(const PX* __restrict__ src, int w, int h, float x, float y, PX out[3]) {
+    const int xf = (int)floorf(x), yf = (int)floorf(y);
+    const float cx = ceilf(x), cy = ceilf(y);
+    const int xc = cx >= (float)(w - 1) ? (w - 1) : (int)cx;
+    const int yc = cy >= (float)(h - 1) ? (h - 1) : (int)cy;
+    const float a = x - (float)xf, b = y - (float)yf;
+    const float w_ld = (1 - a) * (1 - b), w_rd = a * (1 - b), w_rt = a * b, w_lt = (1 - a) * b;
+    const size_t pl = (size_t)w * h;
+    const size_t o_ld = (size_t)yf * w + xf, o_lt = (size_t)yc * w + xf, o_rd = (size_t)yf * w + xc,
+                 o_rt = (size_t)yc * w + xc;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const PX* p = src + c * pl;
+        const float ld = (float)p[o_ld], lt = (float)p[o_lt], rd = (float)p[o_rd], rt = (float)p[o_rt];
+        out[c] = px_store<PX>(w_ld * ld + w_rd * rd + w_rt * rt + w_lt * lt);
+    }
+}
+
+// ---- P1: cylindrical projection, Projection.cpp:20-73 ------------------------------------------------------
+// One output pixel (three channels) per work-item; r is computed on the host (tan).  Writes 0 where the
+// source coordinate falls outside, so no memset pass is needed.
+template <typename PX>
+__global__ __launch_bounds__(256) void k_project(const PX* __restrict__ src, PX* __restrict__ dst, int w, int h,
+                                                 int flag, int width, int height, float r) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const float dst_x = (float)((flag ? y : x) - width / 2);
+    const float dst_y = (float)((flag ? x : y) - height / 2);
+    const double rd = (double)r, dx = (double)dst_x;
+    const float k = (float)(rd / sqrt(rd * rd + dx * dx));
+    const float src_x = dst_x / k, src_y = dst_y / k;
+    const float u = src_x + (float)(width / 2);
+    const float v = src_y + (float)(height / 2);
+    PX o[3] = {PX(0), PX(0), PX(0)};
+    if (u >= 0 && u < (float)width && v >= 0 && v < (float)height) {
+        if (flag)
+            bilinear3<PX>(src, w, h, v, u, o);
+        else
+            bilinear3<PX>(src, w, h, u, v, o);
+    }
+    const size_t pl = (size_t)w * h, off = (size_t)y * w + x;
+    dst[off] = o[0];
+    dst[off + pl] = o[1];
+    dst[off + 2 * pl] = o[2];
+}
+
+// ---- W1: the bilinear map, ImageProcess.cpp:465-471 --------------------------------------------------------
+// double: ((p0*x + p1*y) + (p2*x)*y) + p3, rounded to float; then `int newX = float` truncation.  Values that
+// do not fit an int (x86 gives INT_MIN, which fails the range test) and NaN are reported as "outside".
+__device__ __forceinline__ bool map_to_src(const MapP& m, float fx, float fy, int sw, int sh, int& nx, int& ny) {
+    const double dx = (double)fx, dy = (double)fy;
+    const float X = (float)(m.p[0] * dx + m.p[1] * dy + m.p[2] * dx * dy + m.p[3]);
+    const float Y = (float)(m.p[4] * dx + m.p[5] * dy + m.p[6] * dx * dy + m.p[7]);
+    if (!(X > -2147483648.0f && X < 2147483648.0f) || !(Y > -2147483648.0f && Y < 2147483648.0f)) return false;
+    nx = (int)X;
+    ny = (int)Y;
+    return nx >= 0 && nx < sw && ny >= 0 && ny < sh;
+}
+
+// The degenerate bilinear call of the warp (ImageProcess.cpp:602): a = b = 0, so the value is
+// ((1*1)*ld + (0*1)*rd + (0*0)*rt + (1*0)*lt) = ld*1 + rd*0 + rt*0 + lt*0 with all four taps = ld.
+__device__ __forceinline__ float warp_tap(float ld) { return 1.f * ld + 0.f * ld + 0.f * ld + 0.f * ld; }
+
+// ---- W2 / W3 stand-alone (read-modify-write canvases of the C++ seam) ---------------------------------------
+template <typename PX>
+__global__ __launch_bounds__(256) void k_warp(const PX* __restrict__ src, int sw, int sh, MapP m, float offx,
+                                              float offy, PX* __restrict__ canvas, int cw, int ch) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= cw) return;
+    int nx, ny;
+    if (!map_to_src(m, (float)x + offx, (float)y + offy, sw, sh, nx, ny)) return;
+    const size_t spl = (size_t)sw * sh, so = (size_t)ny * sw + nx, cpl = (size_t)cw * ch, co = (size_t)y * cw + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) canvas[co + c * cpl] = px_store<PX>(warp_tap((float)src[so + c * spl]));
+}
+
+template <typename PX>
+__global__ __launch_bounds__(256) void k_move(const PX* __restrict__ src, int sw, int sh, int ox, int oy,
+                                              PX* __restrict__ canvas, int cw, int ch) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= cw) return;
+    const long long nx = (long long)x + ox, ny = (long long)y + oy;
+    if (nx < 0 || nx >= sw || ny < 0 || ny >= sh) return;
+    const size_t spl = (size_t)sw * sh, so = (size_t)ny * sw + nx, cpl = (size_t)cw * ch, co = (size_t)y * cw + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) canvas[co + c * cpl] = src[so + c * spl];
+}
+
+// ---- S1: compose = warp + move + value cast, straight into the level-0 planes -------------------------------
+// ImageProcess.cpp:218-224 + :680-681.  Level-0 planes: [a0 a1 a2 b0 b1 b2 mask], pitched, plane stride ps.
+// The zero canvases of the reference are implicit: an out-of-range pixel is written as 0.
+template <typename PX>
+__global__ __launch_bounds__(256) void k_compose(const PX* __restrict__ frame, int fw, int fh, MapP m, float offx,
+                                                 float offy, const PX* __restrict__ mosaic, int mw, int mh, int ox,
+                                                 int oy, float* __restrict__ g0, int cw, int ch, int pitch, size_t ps) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= pitch) return;
+    float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
+    if (x < cw) {
+        int nx, ny;
+        if (map_to_src(m, (float)x + offx, (float)y + offy, fw, fh, nx, ny)) {
+            const size_t spl = (size_t)fw * fh, so = (size_t)ny * fw + nx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[c] = (float)px_store<PX>(warp_tap((float)frame[so + c * spl]));
+        }
+        const long long mx = (long long)x + ox, my = (long long)y + oy;
+        if (mx >= 0 && mx < mw && my >= 0 && my < mh) {
+            const size_t spl = (size_t)mw * mh, so = (size_t)my * mw + mx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) b[c] = (float)mosaic[so + c * spl];
+        }
+    }
+    const size_t o = (size_t)y * pitch + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        g0[o + c * ps] = a[c];
+        g0[o + (3 + c) * ps] = b[c];
+    }
+}
+
+// dense canvases a, b (already warped / moved by the caller) -> level-0 planes (stitch_blend_*)
+template <typename PX>
+__global__ __launch_bounds__(256) void k_load_canvases(const PX* __restrict__ a, const PX* __restrict__ b,
+                                                       float* __restrict__ g0, int cw, int ch, int pitch, size_t ps) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= pitch) return;
+    const size_t cpl = (size_t)cw * ch, co = (size_t)y * cw + x, o = (size_t)y * pitch + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        g0[o + c * ps] = x < cw ? (float)a[co + c * cpl] : 0.f;
+        g0[o + (3 + c) * ps] = x < cw ? (float)b[co + c * cpl] : 0.f;
+    }
+}
+
+// ---- B1: seam scan, ImageProcess.cpp:659-671,686-698 --------------------------------------------------------
+// One workgroup walks the middle row of the level-0 planes; integer sums are reduced with wavefront shuffles
+// and one LDS exchange.  Thread 0 derives ratio / ov / branch / start exactly as the reference does.
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void k_seam(const float* __restrict__ g0, int cw, int ch, int pitch, size_t ps,
+                                               int seam_rule, SeamDev* __restrict__ out) {
+    __shared__ int red[4][16];
+    const int mid = ch / 2;
+    const float* a0 = g0 + (size_t)mid * pitch;
+    const float* b0 = a0 + 3 * ps;
+    int s_a = 0, n_a = 0, s_o = 0, n_o = 0;
+    for (int x = threadIdx.x; x < cw; x += blockDim.x) {
+        bool a_on = a0[x] != 0.f, b_on = b0[x] != 0.f;
+        if (seam_rule) {
+            a_on = a_on && a0[x + ps] != 0.f && a0[x + 2 * ps] != 0.f;
+            b_on = b_on && b0[x + ps] != 0.f && b0[x + 2 * ps] != 0.f;
+        }
+        if (a_on) {
+            s_a += x;
+            ++n_a;
+            if (b_on) {
+                s_o += x;
+                ++n_o;
+            }
+        }
+    }
+    s_a = wave_sum(s_a);
+    n_a = wave_sum(n_a);
+    s_o = wave_sum(s_o);
+    n_o = wave_sum(n_o);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[0][wid] = s_a;
+        red[1][wid] = n_a;
+        red[2][wid] = s_o;
+        red[3][wid] = n_o;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        s_a = n_a = s_o = n_o = 0;
+        for (int i = 0; i < nw; ++i) {
+            s_a += red[0][i];
+            n_a += red[1][i];
+            s_o += red[2][i];
+            n_o += red[3][i];
+        }
+        SeamDev s;
+        s.sum_a_x = s_a;
+        s.n_a = n_a;
+        s.sum_ov_x = s_o;
+        s.n_ov = n_o;
+        s.ratio = s.ov = 0.f;
+        s.branch = 1;
+        s.start = cw;  // neutral mask (all zero) when the scan fails
+        s.thr = 0.0;
+        s.status = 0;
+        s.pad = 0;
+        if (n_a == 0)
+            s.status = -2;
+        else if (n_o == 0)
+            s.status = -3;
+        else if (seam_rule == 0) {
+            const float ratio = (float)(1.0 * (double)s_a / (double)n_a);
+            const float ov = (float)(1.0 * (double)s_o / (double)n_o);
+            s.ratio = ratio;
+            s.ov = ov;
+            s.branch = (ratio < ov) ? 0 : 1;
+            s.start = (int)(ov + 1.f);
+            s.thr = (double)ov;
+        } else {
+            const double ratio = (double)s_a / (double)n_a, ov = (double)s_o / (double)n_o;
+            s.ratio = (float)ratio;
+            s.ov = (float)ov;
+            s.branch = (ratio < ov) ? 0 : 1;
+            s.start = (int)(ov + 1.0);
+            s.thr = ov;
+        }
+        *out = s;
+    }
+}
+
+// mask level 0: a vertical step (ImageProcess.cpp:682,690-698), plane 6 of level 0
+__global__ __launch_bounds__(256) void k_mask(float* __restrict__ m0, int cw, int pitch, const SeamDev* __restrict__ seam) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= pitch) return;
+    float v = 0.f;
+    if (x < cw) v = seam->branch == 0 ? ((double)x < seam->thr ? 1.f : 0.f) : (x >= seam->start ? 1.f : 0.f);
+    m0[(size_t)y * pitch + x] = v;
+}
+
+// ---- B3: Van Vliet recursive Gaussian, CImg.h:34887-34932 ---------------------------------------------------
+// The recurrence is strictly sequential along a line (double accumulators that keep their unrounded value,
+// every output stored to float), so the parallel axis is "lines": one line per work-item.
+//
+// x pass: a wavefront owns 64 consecutive rows.  Rows are moved between HBM and LDS as 64x64 tiles with
+// 16-byte-per-lane accesses (a lane loads 4 consecutive samples of one row, 16 lanes cover a 256-byte row
+// segment); in LDS a row is padded to 68 floats so that both the row-wise tile traffic and the per-lane
+// ds_read_b128 of "my row" are bank-conflict free.  The next tile is prefetched into registers while the
+// current one runs its 64 recurrence steps.  The forward kernel leaves (v1,v2,v3,iplus) of every line in
+// `state`; the backward kernel starts from the Triggs boundary values computed from them.
+constexpr int TS = 64;  // tile edge
+constexpr int TP = 68;  // padded LDS row (floats)
+
+__device__ __forceinline__ void tile_load(const float* __restrict__ base, int pitch, int c0, int lane, f4 pre[16]) {
+    // lane -> (row group, 4-column group): rows lane/16 + 4*i, columns 4*(lane%16)..+3
+    const float* p = base + (size_t)(lane >> 4) * pitch + c0 + ((lane & 15) << 2);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pre[i] = *reinterpret_cast<const f4*>(p + (size_t)(4 * i) * pitch);
+}
+__device__ __forceinline__ void tile_to_lds(float* tile, int lane, const f4 pre[16]) {
+    float* t = tile + (lane >> 4) * TP + ((lane & 15) << 2);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<f4*>(t + (4 * i) * TP) = pre[i];
+}
+__device__ __forceinline__ void tile_store(float* __restrict__ base, int pitch, int c0, int lane, const float* tile) {
+    float* p = base + (size_t)(lane >> 4) * pitch + c0 + ((lane & 15) << 2);
+    const float* t = tile + (lane >> 4) * TP + ((lane & 15) << 2);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        *reinterpret_cast<f4*>(p + (size_t)(4 * i) * pitch) = *reinterpret_cast<const f4*>(t + (4 * i) * TP);
+}
+
+// `lines` = rows of all planes stacked (plane stride = pitch*h, so line L starts at L*pitch); the buffers are
+// allocated with 64 spare rows so that a partial last block may touch rows >= lines without leaving them.
+__global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, float* __restrict__ out, int w, int pitch,
+                                                  long lines, VVK k, double* __restrict__ state) {
+    __shared__ __attribute__((aligned(16))) float tile[TS * TP];
+    const int lane = threadIdx.x;
+    const long line0 = (long)blockIdx.x * TS, line = line0 + lane;
+    const float* ib = in + (size_t)line0 * pitch;
+    float* ob = out + (size_t)line0 * pitch;
+    const int ntiles = (w + TS - 1) / TS;
+    const bool live = line < lines;
+    double iplus = live ? (double)in[(size_t)line * pitch + (w - 1)] : 0.0;  // CImg.h:34906
+    double v1 = 0, v2 = 0, v3 = 0;
+    f4 pre[16];
+    tile_load(ib, pitch, 0, lane, pre);
+    for (int t = 0; t < ntiles; ++t) {
+        tile_to_lds(tile, lane, pre);
+        if (t + 1 < ntiles) tile_load(ib, pitch, (t + 1) * TS, lane, pre);
+        __syncthreads();  // one wave per workgroup: orders the tile writes before the per-lane row reads
+        float* row = tile + lane * TP;
+        const int jmax = min(TS, w - t * TS);
+        if (t == 0) v1 = v2 = v3 = (double)row[0] / k.sumsq;  // CImg.h:34909
+        const int jfull = jmax & ~15;
+        for (int jb = 0; jb < jfull; jb += 16) {
+            float xs[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f4*>(xs + 4 * q) = *reinterpret_cast<const f4*>(row + jb + 4 * q);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                double v0 = (double)xs[u];
+                v0 += v1 * k.f1;
+                v0 += v2 * k.f2;
+                v0 += v3 * k.f3;
+                xs[u] = (float)v0;
+                v3 = v2;
+                v2 = v1;
+                v1 = v0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f4*>(row + jb + 4 * q) = *reinterpret_cast<const f4*>(xs + 4 * q);
+        }
+        for (int j = jfull; j < jmax; ++j) {  // ragged tail of the last tile, straight from LDS
+            double v0 = (double)row[j];
+            v0 += v1 * k.f1;
+            v0 += v2 * k.f2;
+            v0 += v3 * k.f3;
+            row[j] = (float)v0;
+            v3 = v2;
+            v2 = v1;
+            v1 = v0;
+        }
+        __syncthreads();
+        tile_store(ob, pitch, t * TS, lane, tile);
+    }
+    if (live) {
+        state[line] = v1;
+        state[lines + line] = v2;
+        state[2 * lines + line] = v3;
+        state[3 * lines + line] = iplus;
+    }
+}
+
+__device__ __forceinline__ void triggs(const VVK& k, double iplus, double& v1, double& v2, double& v3, float& first) {
+    // CImg.h:34911-34922
+    const double uplus = iplus / k.den, vplus = uplus / k.den, unp = v1 - uplus, unp1 = v2 - uplus, unp2 = v3 - uplus;
+    const double n0 = (k.M[0] * unp + k.M[1] * unp1 + k.M[2] * unp2 + vplus) * k.sum;
+    const double n1 = (k.M[3] * unp + k.M[4] * unp1 + k.M[5] * unp2 + vplus) * k.sum;
+    const double n2 = (k.M[6] * unp + k.M[7] * unp1 + k.M[8] * unp2 + vplus) * k.sum;
+    first = (float)n0;
+    v3 = n2;
+    v2 = n1;
+    v1 = n0;
+}
+
+__global__ __launch_bounds__(64) void k_vv_x_bwd(float* __restrict__ data, int w, int pitch, long lines, VVK k,
+                                                  const double* __restrict__ state) {
+    __shared__ __attribute__((aligned(16))) float tile[TS * TP];
+    const int lane = threadIdx.x;
+    const long line0 = (long)blockIdx.x * TS, line = line0 + lane;
+    float* base = data + (size_t)line0 * pitch;
+    const int ntiles = (w + TS - 1) / TS;
+    const bool live = line < lines;
+    double v1 = 0, v2 = 0, v3 = 0, iplus = 0;
+    if (live) {
+        v1 = state[line];
+        v2 = state[lines + line];
+        v3 = state[2 * lines + line];
+        iplus = state[3 * lines + line];
+    }
+    float first;
+    triggs(k, iplus, v1, v2, v3, first);
+    f4 pre[16];
+    tile_load(base, pitch, (ntiles - 1) * TS, lane, pre);
+    for (int t = ntiles - 1; t >= 0; --t) {
+        tile_to_lds(tile, lane, pre);
+        if (t > 0) tile_load(base, pitch, (t - 1) * TS, lane, pre);
+        __syncthreads();
+        float* row = tile + lane * TP;
+        int jtop = min(TS, w - t * TS);  // samples [0,jtop) of this tile, processed from jtop-1 down to 0
+        if (t == ntiles - 1) {
+            row[jtop - 1] = first;  // sample N-1 takes the boundary value (CImg.h:34920)
+            --jtop;
+        }
+        // whole 16-sample groups below jtop, then the ragged top group first (descending order overall)
+        const int jfull = jtop & ~15;
+        if (jtop > jfull) {
+            for (int j = jtop - 1; j >= jfull; --j) {
+                double v0 = (double)row[j];
+                v0 *= k.sum;
+                v0 += v1 * k.f1;
+                v0 += v2 * k.f2;
+                v0 += v3 * k.f3;
+                row[j] = (float)v0;
+                v3 = v2;
+                v2 = v1;
+                v1 = v0;
+            }
+        }
+        for (int jb = jfull - 16; jb >= 0; jb -= 16) {
+            float xs[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f4*>(xs + 4 * q) = *reinterpret_cast<const f4*>(row + jb + 4 * q);
+#pragma unroll
+            for (int u = 15; u >= 0; --u) {
+                double v0 = (double)xs[u];
+                v0 *= k.sum;
+                v0 += v1 * k.f1;
+                v0 += v2 * k.f2;
+                v0 += v3 * k.f3;
+                xs[u] = (float)v0;
+                v3 = v2;
+                v2 = v1;
+                v1 = v0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f4*>(row + jb + 4 * q) = *reinterpret_cast<const f4*>(xs + 4 * q);
+        }
+        __syncthreads();
+        tile_store(base, pitch, t * TS, lane, tile);
+    }
+}
+
+// y pass: one column per work-item, so a wavefront reads/writes 256 contiguous bytes of one row per step.
+// Rows are fetched UY at a time ahead of the recurrence.  In place.  grid = (pitch/64, planes).
+constexpr int UY = 8;
+
+__global__ __launch_bounds__(64) void k_vv_y_fwd(float* __restrict__ data, int h, int pitch, size_t ps, VVK k,
+                                                  double* __restrict__ state) {
+    const int x = blockIdx.x * WAVE + threadIdx.x;
+    float* p = data + blockIdx.y * ps + x;
+    const double iplus = (double)p[(size_t)(h - 1) * pitch];
+    double v1, v2, v3;
+    v1 = v2 = v3 = (double)p[0] / k.sumsq;
+    float cur[UY], nxt[UY];
+#pragma unroll
+    for (int u = 0; u < UY; ++u) cur[u] = u < h ? p[(size_t)u * pitch] : 0.f;
+    for (int y0 = 0; y0 < h; y0 += UY) {
+#pragma unroll
+        for (int u = 0; u < UY; ++u) nxt[u] = (y0 + UY + u) < h ? p[(size_t)(y0 + UY + u) * pitch] : 0.f;
+#pragma unroll
+        for (int u = 0; u < UY; ++u) {
+            if (y0 + u < h) {
+                double v0 = (double)cur[u];
+                v0 += v1 * k.f1;
+                v0 += v2 * k.f2;
+                v0 += v3 * k.f3;
+                p[(size_t)(y0 + u) * pitch] = (float)v0;
+                v3 = v2;
+                v2 = v1;
+                v1 = v0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UY; ++u) cur[u] = nxt[u];
+    }
+    const size_t n = (size_t)gridDim.x * WAVE * gridDim.y, i = (size_t)blockIdx.y * gridDim.x * WAVE + x;
+    state[i] = v1;
+    state[n + i] = v2;
+    state[2 * n + i] = v3;
+    state[3 * n + i] = iplus;
+}
+
+__global__ __launch_bounds__(64) void k_vv_y_bwd(float* __restrict__ data, int h, int pitch, size_t ps, VVK k,
+                                                  const double* __restrict__ state) {
+    const int x = blockIdx.x * WAVE + threadIdx.x;
+    float* p = data + blockIdx.y * ps + x;
+    const size_t n = (size_t)gridDim.x * WAVE * gridDim.y, i = (size_t)blockIdx.y * gridDim.x * WAVE + x;
+    double v1 = state[i], v2 = state[n + i], v3 = state[2 * n + i];
+    const double iplus = state[3 * n + i];
+    float first;
+    triggs(k, iplus, v1, v2, v3, first);
+    p[(size_t)(h - 1) * pitch] = first;
+    // remaining samples h-2 .. 0
+    float cur[UY], nxt[UY];
+    int top = h - 2;  // next sample to process
+#pragma unroll
+    for (int u = 0; u < UY; ++u) cur[u] = (top - u) >= 0 ? p[(size_t)(top - u) * pitch] : 0.f;
+    for (; top >= 0; top -= UY) {
+#pragma unroll
+        for (int u = 0; u < UY; ++u) nxt[u] = (top - UY - u) >= 0 ? p[(size_t)(top - UY - u) * pitch] : 0.f;
+#pragma unroll
+        for (int u = 0; u < UY; ++u) {
+            if (top - u >= 0) {
+                double v0 = (double)cur[u];
+                v0 *= k.sum;
+                v0 += v1 * k.f1;
+                v0 += v2 * k.f2;
+                v0 += v3 * k.f3;
+                p[(size_t)(top - u) * pitch] = (float)v0;
+                v3 = v2;
+                v2 = v1;
+                v1 = v0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UY; ++u) cur[u] = nxt[u];
+    }
+}
+
+// ---- B3': Deriche order 0, CImg.h:34779-34797 (all float).  The causal pass needs a line of temporaries Y; the
+// anticausal pass adds Y back.  One line per work-item, y pass only coalesced; the x pass reuses the y kernel on
+// a transposed view is NOT possible in place, so x runs one row per work-item straight from global memory
+// (ex6 variant; not on the benchmarked path).
+__global__ __launch_bounds__(64) void k_deriche(float* __restrict__ data, float* __restrict__ Y, int N, size_t off,
+                                                size_t line_stride, long lines_per_plane, size_t ps, long lines, DRK k) {
+    const long line = (long)blockIdx.x * WAVE + threadIdx.x;
+    if (line >= lines) return;
+    const long plane = line / lines_per_plane, li = line % lines_per_plane;
+    float* ptrX = data + plane * ps + li * line_stride;
+    float* ptrY = Y + plane * ps + li * line_stride;
+    float xp = *ptrX, yb, yp;
+    yb = yp = (float)(k.coefp * xp);
+    for (int m = 0; m < N; ++m) {
+        const float xc = ptrX[(size_t)m * off];
+        const float yc = k.a0 * xc + k.a1 * xp - k.b1 * yp - k.b2 * yb;
+        ptrY[(size_t)m * off] = yc;
+        xp = xc;
+        yb = yp;
+        yp = yc;
+    }
+    float xn, xa, yn, ya;
+    xn = xa = ptrX[(size_t)(N - 1) * off];
+    yn = ya = k.coefn * xn;
+    for (int n = N - 1; n >= 0; --n) {
+        const float xc = ptrX[(size_t)n * off];
+        const float yc = k.a2 * xn + k.a3 * xa - k.b1 * yn - k.b2 * ya;
+        xa = xn;
+        xn = xc;
+        ya = yn;
+        yn = yc;
+        ptrX[(size_t)n * off] = ptrY[(size_t)n * off] + yc;
+    }
+}
+
+// ---- B4: moving-average decimation, CImg.h:29539-29575 -------------------------------------------------------
+// Output t of an axis accumulates, in increasing s, src[s]*(float)d into a float that starts at 0, where d is
+// the overlap of [t*n_src,(t+1)*n_src) with [s*n_dst,(s+1)*n_dst), then divides once by (float)n_src.  x first
+// (result rounded to float), then y -- both inside one work-item, which owns one output sample of one plane.
+struct Taps {  // up to 4 overlaps per output sample (3 when n_src = 2*n_dst+1, 2 when n_src = 2*n_dst)
+    int s0, n;
+    float d[4];
+};
+__device__ __forceinline__ Taps make_taps(int t, int n_src, int n_dst) {
+    Taps r;
+    const long long pos = (long long)t * n_src;
+    int s = (int)(pos / n_dst);
+    int c_left = (int)((long long)(s + 1) * n_dst - pos);
+    int remaining = n_src;
+    r.s0 = s;
+    r.n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = remaining < c_left ? remaining : c_left;
+        r.d[i] = (float)(unsigned)d;
+        if (d > 0) r.n = i + 1;
+        remaining -= d;
+        c_left = n_dst;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_decimate(const float* __restrict__ src, int w, int h, int spitch, size_t sps,
+                                                  float* __restrict__ dst, int w2, int h2, int dpitch, size_t dps) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, pl = blockIdx.z;
+    if (x >= dpitch) return;
+    float out = 0.f;
+    if (x < w2) {
+        const Taps tx = make_taps(x, w, w2), ty = make_taps(y, h, h2);
+        const float* p = src + pl * sps + tx.s0;
+        const float fw = (float)(unsigned)w, fh = (float)(unsigned)h;
+        float acc_y = 0.f;
+        for (int j = 0; j < ty.n; ++j) {
+            const float* row = p + (size_t)(ty.s0 + j) * spitch;
+            float acc = 0.f;
+            for (int i = 0; i < tx.n; ++i) acc += row[i] * tx.d[i];
+            acc /= fw;
+            acc_y += acc * ty.d[j];
+        }
+        out = acc_y / fh;
+    }
+    dst[pl * dps + (size_t)y * dpitch + x] = out;
+}
+
+// ---- B5/B6: expand, Laplacian, per-level blend, collapse -----------------------------------------------------
+// CImg.h:29618-29690 linear interpolation: out = (float)((1-alpha)*v1 + alpha*v2) in double with
+// v2 = v1 at the last source sample; the x pass is rounded to float before the y pass.  Index/alpha tables are
+// the reference's serial `curr = min(n_src-1, curr+f)` walk, computed on the host.  A source axis of length 1
+// is nearest-neighbour (:29620, :29657).
+struct ExpandTab {
+    const int32_t* ix;
+    const double* ax;
+    const int32_t* iy;
+    const double* ay;
+};
+
+__device__ __forceinline__ float lerp_ref(double alpha, float v1, float v2) {
+    return (float)((1 - alpha) * (double)v1 + alpha * (double)v2);
+}
+
+struct ExpandPos {  // everything about (x,y) that does not depend on the plane
+    int o11, o12, o21, o22;
+    double ax, ay;
+    bool x_nearest, y_nearest;
+};
+__device__ __forceinline__ ExpandPos expand_pos(const ExpandTab& tb, int x, int y, int sw, int sh, int spitch) {
+    ExpandPos e;
+    const int ix = tb.ix[x], iy = tb.iy[y];
+    const int ix2 = ix < sw - 1 ? ix + 1 : ix, iy2 = iy < sh - 1 ? iy + 1 : iy;
+    e.ax = tb.ax[x];
+    e.ay = tb.ay[y];
+    e.o11 = iy * spitch + ix;
+    e.o12 = iy * spitch + ix2;
+    e.o21 = iy2 * spitch + ix;
+    e.o22 = iy2 * spitch + ix2;
+    e.x_nearest = (sw == 1);
+    e.y_nearest = (sh == 1);
+    return e;
+}
+__device__ __forceinline__ float expand_at(const float* __restrict__ pl, const ExpandPos& e) {
+    float r1, r2;
+    if (e.x_nearest) {
+        r1 = pl[e.o11];
+        r2 = pl[e.o21];
+    } else {
+        r1 = lerp_ref(e.ax, pl[e.o11], pl[e.o12]);
+        r2 = lerp_ref(e.ax, pl[e.o21], pl[e.o22]);
+    }
+    return e.y_nearest ? r1 : lerp_ref(e.ay, r1, r2);
+}
+
+// blend of one sample, ImageProcess.cpp:749-751: a*m is a float product, b*(1.0-m) and the sum are double.
+__device__ __forceinline__ float blend_ref(float a, float b, float m) {
+    const float am = a * m;
+    return (float)((double)am + (double)b * (1.0 - (double)m));
+}
+
+// top level: E = a*m + b*(1-m) on the Gaussian top (no Laplacian, no clamp); E has 3 pitched planes.
+__global__ __launch_bounds__(256) void k_blend_top(const float* __restrict__ g, int pitch, int h, size_t ps,
+                                                   float* __restrict__ e) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= pitch) return;
+    const size_t o = (size_t)y * pitch + x;
+    const float m = g[o + 6 * ps];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) e[o + c * ps] = blend_ref(g[o + c * ps], g[o + (3 + c) * ps], m);
+}
+
+// level l < L-1:  La = Ga_l - EXPAND(Ga_{l+1}), Lb likewise (float subtract, CImg.h:12096-12107);
+// S = blend(La, Lb, m_l);  E_l = clamp(S + EXPAND(E_{l+1}), 0, 255) (ImageProcess.cpp:766-769).
+// OUT = float planes (pitched, next collapse input) or the final dense canvas (float, or uint8_t by truncation).
+template <typename OUT, bool DENSE>
+__global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g, int w, int h, int pitch, size_t ps,
+                                                  const float* __restrict__ gn, const float* __restrict__ en, int sw,
+                                                  int sh, int spitch, size_t sps, ExpandTab tb, OUT* __restrict__ out,
+                                                  int opitch, size_t ops) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= (DENSE ? w : pitch)) return;
+    if (!DENSE && x >= w) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(size_t)y * opitch + x + c * ops] = OUT(0);
+        return;
+    }
+    const ExpandPos e = expand_pos(tb, x, y, sw, sh, spitch);
+    const size_t o = (size_t)y * pitch + x;
+    const float m = g[o + 6 * ps];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float la = g[o + c * ps] - expand_at(gn + c * sps, e);
+        const float lb = g[o + (3 + c) * ps] - expand_at(gn + (3 + c) * sps, e);
+        const float s = blend_ref(la, lb, m);
+        float v = s + expand_at(en + c * sps, e);
+        if (v > 255.f)
+            v = 255.f;
+        else if (v < 0.f)
+            v = 0.f;
+        out[(size_t)y * opitch + x + c * ops] = px_store<OUT>(v);
+    }
+}
+
+// single-level pyramid (max side 2 or 3): the result is the top-level blend itself, cast to the output type
+template <typename OUT>
+__global__ void k_emit_top(const float* __restrict__ e, int w, int h, int pitch, size_t ps, OUT* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(size_t)c * w * h + (size_t)y * w + x] = px_store<OUT>(e[(size_t)y * pitch + x + c * ps]);
+}
+
+// ---- E1-E3 / M1: equalisation and luminance mix --------------------------------------------------------------
+__device__ __forceinline__ float clamp256(float v) { return v > 0 ? (v < 256 ? v : 255.f) : 0.f; }
+// equalization.cpp:78-80 / ImageProcess.cpp:242-244: double expressions, float store, float clamp
+__device__ __forceinline__ void rgb_to_ycc(float r, float g, float b, float& Y, float& Cb, float& Cr) {
+    Y = clamp256((float)(0.299 * (double)r + 0.857 * (double)g + 0.114 * (double)b));  // 0.857 sic
+    Cb = clamp256((float)(128.0 - 0.168736 * (double)r - 0.331264 * (double)g + 0.5 * (double)b));
+    Cr = clamp256((float)(128.0 + 0.5 * (double)r - 0.418688 * (double)g - 0.081312 * (double)b));
+}
+// equalization.cpp:93-98 / ImageProcess.cpp:262-267
+__device__ __forceinline__ void ycc_to_rgb_u8(float Y, float Cb, float Cr, uint8_t& r, uint8_t& g, uint8_t& b) {
+    const float R = (float)((double)Y + 1.402 * ((double)Cr - 128.0));
+    const float G = (float)((double)Y - 0.34414 * ((double)Cb - 128.0) - 0.71414 * ((double)Cr - 128.0));
+    const float B = (float)((double)Y + 1.772 * ((double)Cb - 128.0));
+    r = (uint8_t)(int)clamp256(R);
+    g = (uint8_t)(int)clamp256(G);
+    b = (uint8_t)(int)clamp256(B);
+}
+
+// Y histogram (equalization.cpp:104-107): each wavefront owns a private 256-bin LDS histogram (no cross-wave
+// contention), the workgroup's wavefronts are summed through LDS, and each bin is flushed with one global
+// atomic per workgroup.  Four pixels per work-item per step (uchar4 loads when the plane size allows).
+constexpr int HIST_WAVES = 4;
+__global__ __launch_bounds__(HIST_WAVES * 64) void k_hist(const uint8_t* __restrict__ img, size_t n, int32_t* __restrict__ hist) {
+    __shared__ int lh[HIST_WAVES][256];
+    const int wid = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < HIST_WAVES * 256; i += blockDim.x) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float Y, Cb, Cr;
+        rgb_to_ycc((float)img[i], (float)img[i + n], (float)img[i + 2 * n], Y, Cb, Cr);
+        atomicAdd(&lh[wid][(uint8_t)(int)Y], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) {
+        int s = 0;
+#pragma unroll
+        for (int k2 = 0; k2 < HIST_WAVES; ++k2) s += lh[k2][b];
+        if (s) atomicAdd(&hist[b], s);
+    }
+}
+
+// CDF and LUT (equalization.cpp:110-124): 256 sequential double additions -- kept sequential on one lane so
+// that the running sum is bit-identical; round() is half-away-from-zero.
+__global__ void k_lut(const int32_t* __restrict__ hist, int w, int h, int32_t* __restrict__ lut) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double total = (double)(w * h);
+    double cdf = 0.0;
+    for (int i = 0; i < 256; ++i) {
+        const double p = (double)hist[i] / total;
+        cdf = (i == 0) ? p : cdf + p;
+        lut[i] = (int32_t)round(255.0 * cdf);
+    }
+}
+
+// apply (equalization.cpp:127-130 + :92-99), in place; FUSE_MIX additionally performs M1 so that the equalised
+// copy never exists in memory (stitch_dev_finish_u8).
+template <bool FUSE_MIX>
+__global__ __launch_bounds__(256) void k_equalize_apply(uint8_t* __restrict__ img, size_t n, const int32_t* __restrict__ lut,
+                                                        double num, double den) {
+    __shared__ int slut[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) slut[i] = lut[i];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float r = (float)img[i], g = (float)img[i + n], b = (float)img[i + 2 * n];
+        float Y, Cb, Cr;
+        rgb_to_ycc(r, g, b, Y, Cb, Cr);
+        const uint8_t yq = (uint8_t)(int)Y, cbq = (uint8_t)(int)Cb, crq = (uint8_t)(int)Cr;  // CImg<uchar> store
+        const uint8_t yeq = (uint8_t)slut[yq];
+        uint8_t er, eg, eb;
+        ycc_to_rgb_u8((float)yeq, (float)cbq, (float)crq, er, eg, eb);
+        if (FUSE_MIX) {
+            float Ye, Cbe, Cre;
+            rgb_to_ycc((float)er, (float)eg, (float)eb, Ye, Cbe, Cre);
+            const float Ym = (float)((double)Y * num / den + (double)Ye / den);  // ImageProcess.cpp:261
+            ycc_to_rgb_u8(Ym, Cb, Cr, er, eg, eb);
+        }
+        img[i] = er;
+        img[i + n] = eg;
+        img[i + 2 * n] = eb;
+    }
+}
+
+// M1 stand-alone, ImageProcess.cpp:240-268
+__global__ __launch_bounds__(256) void k_lummix(uint8_t* __restrict__ res, const uint8_t* __restrict__ eq, size_t n, double num,
+                                                double den) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float Y, Cb, Cr, Ye, Cbe, Cre;
+        rgb_to_ycc((float)res[i], (float)res[i + n], (float)res[i + 2 * n], Y, Cb, Cr);
+        rgb_to_ycc((float)eq[i], (float)eq[i + n], (float)eq[i + 2 * n], Ye, Cbe, Cre);
+        const float Ym = (float)((double)Y * num / den + (double)Ye / den);
+        uint8_t r, g, b;
+        ycc_to_rgb_u8(Ym, Cb, Cr, r, g, b);
+        res[i] = r;
+        res[i + n] = g;
+        res[i + 2 * n] = b;
+    }
+}
+
+}  // namespace sk

@@ -1,0 +1,166 @@
+/* stitch.h -- C ABI of the MI355X-native stitching hot path (libstitch_hip.so).
+ *
+ * This is the drop-in boundary for the per-pixel path of chensh236/ComputerVisionImageStich2.  The reference
+ * has no FFI: the path sits behind ordinary C++ functions on CImg<unsigned char>.  Each entry point below
+ * names the reference interface it replaces (file:line under /root/reference); the C++ adaptor that
+ * re-exposes the reference's own symbols on top of this ABI is
+ * computervisionimagestich2_amd/adaptor/cimg_dropin.cpp.
+ *
+ * Conventions
+ *   - Images are planar, channel-major buffers exactly as CImg lays them out (CImg.h:11787-11793):
+ *     offset = x + y*W + c*W*H, 3 channels, so an adaptor passes img._data / _width / _height with no repack.
+ *   - `_u8` entry points are the reference's own contract (CImg<unsigned char> in/out, results bit-identical
+ *     to the reference).  `_f32` twins run the same arithmetic on float frames and skip the final
+ *     float->uchar truncation (the metric's 4096x4096x3 f32 frames).
+ *   - Plain entry points take HOST pointers, run on the current HIP device and return when the result is in
+ *     the output buffer.  `stitch_dev_*` entry points take DEVICE pointers, enqueue on `stream`
+ *     (a hipStream_t passed as void*) and return without synchronising.
+ *   - Return value: STITCH_OK or a negative stitch_status; stitch_last_error() gives the text (thread local).
+ *   - Every kernel is hand-written HIP for gfx950.  There is no CPU fallback: without a HIP device every
+ *     compute entry point fails with STITCH_ERR_NO_DEVICE.
+ */
+#ifndef STITCH_H
+#define STITCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STITCH_ABI_VERSION 1
+
+typedef enum stitch_status {
+    STITCH_OK = 0,
+    STITCH_ERR_ARG = -1,          /* null pointer / non-positive size / bad option                              */
+    STITCH_ERR_EMPTY_MIDROW = -2, /* channel 0 of a's middle row is all zero: the reference never terminates
+                                     (ImageProcess.cpp:661)                                                      */
+    STITCH_ERR_ZERO_OVERLAP = -3, /* a and b do not overlap on the middle row: the reference divides 0/0
+                                     (ImageProcess.cpp:687)                                                      */
+    STITCH_ERR_PYRAMID = -4,      /* a pyramid level would have a zero dimension (min side < 2^(levels-1))       */
+    STITCH_ERR_HIP = -5,          /* a HIP runtime call failed; text in stitch_last_error()                      */
+    STITCH_ERR_NO_DEVICE = -6     /* no HIP device visible                                                       */
+} stitch_status;
+
+/* Parameters of the multi-band blend.  stitch_blend_opts_default() = the root variant the oracle follows. */
+typedef struct stitch_blend_opts {
+    float sigma;    /* REDUCE blur sigma; reference: 2 (ImageProcess.cpp:709)                                    */
+    int blur_kind;  /* 0 = Van Vliet, get_blur(2,true,true) (ImageProcess.cpp:709-714, CImg.h:35045-35091);
+                       1 = Deriche, get_blur(2) (src/ex6/ImageProcess.cpp:702-705, CImg.h:34777-34869)           */
+    int level_rule; /* 0 = floor(log2(max(w,h))) (ImageProcess.cpp:675-676); 1 = min (src/ex6 :662-665)          */
+    int seam_rule;  /* 0 = channel 0 decides "non-empty", float ratios (ImageProcess.cpp:659-698);
+                       1 = all three channels, double ratios (src/ex6/ImageProcess.cpp:641-698)                  */
+} stitch_blend_opts;
+
+/* What the seam scan found (ImageProcess.cpp:659-671,686-698). */
+typedef struct stitch_seam {
+    int32_t sum_a_x, n_a, sum_ov_x, n_ov; /* the four mid-row integers                                           */
+    float ratio, ov;                      /* sum_a_x/n_a and sum_ov_x/n_ov                                       */
+    int32_t branch;                       /* 0: mask = 1 where x < ov; 1: mask = 1 where x >= start              */
+    int32_t start;                        /* (int)(ov + 1)                                                       */
+} stitch_seam;
+
+typedef struct stitch_plan stitch_plan; /* device workspace of one canvas size: pyramids, tables, scratch */
+
+/* ---- library ------------------------------------------------------------------------------------------- */
+int stitch_abi_version(void);
+const char *stitch_last_error(void);
+int stitch_device_count(void);       /* number of HIP devices, 0 if none */
+int stitch_set_device(int ordinal);  /* hipSetDevice for the calling thread */
+void stitch_blend_opts_default(stitch_blend_opts *o);
+/* Pyramid shape for a canvas (ImageProcess.cpp:675-676,705-708).  Returns the level count (>0) or a status;
+ * level_w/level_h (capacity 32) may be NULL. */
+int stitch_pyramid_levels(int w, int h, int level_rule, int *level_w, int *level_h);
+
+/* ---- host-buffer entry points (what the C++ adaptor binds) ---------------------------------------------- */
+/* Projection::imageProjection + bilinearInterpolation, Projection.cpp:3-73.  fov_deg = ANGLE (Projection.h:13). */
+int stitch_project_u8(const uint8_t *src, int w, int h, float fov_deg, uint8_t *dst);
+int stitch_project_f32(const float *src, int w, int h, float fov_deg, float *dst);
+/* ImageProcess::warpingImageByHomography (+ getX/YAfterWarping), ImageProcess.cpp:465-471,596-606.
+ * p = {H00,H01,H02,H10,H11,H12,H20,H21} of `Homography` (ImageProcess.h:58-73).  The canvas is read-modify-
+ * write: pixels whose source falls outside `src` keep the caller's value (the reference pre-zeroes it, :218). */
+int stitch_warp_u8(const uint8_t *src, int sw, int sh, const double p[8], float offx, float offy, uint8_t *canvas,
+                   int cw, int ch);
+int stitch_warp_f32(const float *src, int sw, int sh, const double p[8], float offx, float offy, float *canvas,
+                    int cw, int ch);
+/* ImageProcess::movingImageByOffset, ImageProcess.cpp:608-620 (same read-modify-write rule). */
+int stitch_move_u8(const uint8_t *src, int sw, int sh, int ox, int oy, uint8_t *canvas, int cw, int ch);
+int stitch_move_f32(const float *src, int sw, int sh, int ox, int oy, float *canvas, int cw, int ch);
+/* ImageProcess::blendTwoImages, ImageProcess.cpp:648-773 (opts NULL = defaults).  seam_out may be NULL. */
+int stitch_blend_u8(const uint8_t *a, const uint8_t *b, int w, int h, const stitch_blend_opts *opts, uint8_t *out,
+                    stitch_seam *seam_out);
+int stitch_blend_f32(const float *a, const float *b, int w, int h, const stitch_blend_opts *opts, float *out,
+                     stitch_seam *seam_out);
+/* One stitch step, ImageProcess.cpp:218-230: zero canvases a,b; warp `frame` into a; move `mosaic` into b;
+ * out = blendTwoImages(a,b).  The canvases never leave the device. */
+int stitch_pair_u8(const uint8_t *frame, int fw, int fh, const double p[8], float offx, float offy,
+                   const uint8_t *mosaic, int mw, int mh, int ox, int oy, int cw, int ch,
+                   const stitch_blend_opts *opts, uint8_t *out, stitch_seam *seam_out);
+int stitch_pair_f32(const float *frame, int fw, int fh, const double p[8], float offx, float offy,
+                    const float *mosaic, int mw, int mh, int ox, int oy, int cw, int ch,
+                    const stitch_blend_opts *opts, float *out, stitch_seam *seam_out);
+/* equalization::equalization(src, 1), equalization.cpp:4-25,74-131: in place.  hist_out (optional) receives
+ * the 256 Y-histogram bins of equalizationStep (:104-107). */
+int stitch_equalize_u8(uint8_t *img, int w, int h, int32_t hist_out[256]);
+/* Luminance mix inlined in ImageProcess::matching, ImageProcess.cpp:240-268:
+ * Y = Y*num/den + Yeq/den (reference 19,20; src/ex6 5,6); in place on `result`. */
+int stitch_lummix_u8(uint8_t *result, const uint8_t *equalized, int w, int h, double num, double den);
+/* The tail of matching() as one call, ImageProcess.cpp:237-268: tmp = result; equalization(tmp,1); mix. */
+int stitch_finish_u8(uint8_t *result, int w, int h, double num, double den, int32_t hist_out[256]);
+
+/* ---- device-resident entry points (asynchronous on `stream`) -------------------------------------------- */
+int stitch_dev_project_u8(const uint8_t *d_src, int w, int h, float fov_deg, uint8_t *d_dst, void *stream);
+int stitch_dev_project_f32(const float *d_src, int w, int h, float fov_deg, float *d_dst, void *stream);
+int stitch_dev_warp_u8(const uint8_t *d_src, int sw, int sh, const double p[8], float offx, float offy,
+                       uint8_t *d_canvas, int cw, int ch, void *stream);
+int stitch_dev_warp_f32(const float *d_src, int sw, int sh, const double p[8], float offx, float offy,
+                        float *d_canvas, int cw, int ch, void *stream);
+int stitch_dev_move_u8(const uint8_t *d_src, int sw, int sh, int ox, int oy, uint8_t *d_canvas, int cw, int ch,
+                       void *stream);
+int stitch_dev_move_f32(const float *d_src, int sw, int sh, int ox, int oy, float *d_canvas, int cw, int ch,
+                        void *stream);
+
+/* A plan owns every device buffer a cw x ch blend needs (Gaussian/Laplacian pyramids of a, b and the mask,
+ * the blur scratch, the collapse chain, the resize tables, the seam record).  Create it once per canvas size
+ * on the device that will run it; calls on one plan must be serialised by the caller (one stream at a time). */
+int stitch_plan_create(int cw, int ch, const stitch_blend_opts *opts, stitch_plan **plan_out);
+void stitch_plan_destroy(stitch_plan *plan);
+size_t stitch_plan_workspace_bytes(const stitch_plan *plan);
+int stitch_plan_levels(const stitch_plan *plan, int *level_w, int *level_h);
+
+int stitch_dev_blend_u8(stitch_plan *plan, const uint8_t *d_a, const uint8_t *d_b, uint8_t *d_out, void *stream);
+int stitch_dev_blend_f32(stitch_plan *plan, const float *d_a, const float *d_b, float *d_out, void *stream);
+int stitch_dev_pair_u8(stitch_plan *plan, const uint8_t *d_frame, int fw, int fh, const double p[8], float offx,
+                       float offy, const uint8_t *d_mosaic, int mw, int mh, int ox, int oy, uint8_t *d_out,
+                       void *stream);
+int stitch_dev_pair_f32(stitch_plan *plan, const float *d_frame, int fw, int fh, const double p[8], float offx,
+                        float offy, const float *d_mosaic, int mw, int mh, int ox, int oy, float *d_out, void *stream);
+/* Waits for the plan's last call to finish and reports its seam outcome: STITCH_OK, STITCH_ERR_EMPTY_MIDROW or
+ * STITCH_ERR_ZERO_OVERLAP (in the error cases the output buffer holds unspecified finite values). */
+int stitch_plan_status(stitch_plan *plan, stitch_seam *seam_out);
+
+/* Per-stage device timing of a plan's calls, with HIP events on the call's stream.  Stage ids: */
+enum {
+    STITCH_STAGE_COMPOSE = 0, /* warp + move (+ value cast) -> level-0 planes, seam scan, mask step             */
+    STITCH_STAGE_BLUR_X = 1,  /* recursive Gaussian along rows, all levels                                       */
+    STITCH_STAGE_BLUR_Y = 2,  /* recursive Gaussian along columns, all levels                                    */
+    STITCH_STAGE_DECIMATE = 3,/* moving-average halving, all levels                                              */
+    STITCH_STAGE_COLLAPSE = 4,/* expand + Laplacian + per-level blend + collapse, all levels                     */
+    STITCH_STAGE_COUNT = 5
+};
+int stitch_plan_set_profiling(stitch_plan *plan, int enabled);
+/* Sums (ms) and launch counts per stage since profiling was enabled or last read; synchronises the stream.
+ * level0_ms[stage] = the share of the finest level alone (the dominant launch of each stage). */
+int stitch_plan_read_profile(stitch_plan *plan, double stage_ms[STITCH_STAGE_COUNT],
+                             int stage_launches[STITCH_STAGE_COUNT], double level0_ms[STITCH_STAGE_COUNT]);
+
+int stitch_dev_equalize_u8(uint8_t *d_img, int w, int h, int32_t *d_hist256, void *stream);
+int stitch_dev_lummix_u8(uint8_t *d_result, const uint8_t *d_equalized, int w, int h, double num, double den,
+                         void *stream);
+int stitch_dev_finish_u8(uint8_t *d_result, int w, int h, double num, double den, int32_t *d_hist256, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STITCH_H */
