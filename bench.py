@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- warp+blend MPix/s at 4096x4096x3 f32 (BASELINE.json), one process per GPU.
+
+A step = one pass of the hot path (warp + move + multi-band blend) over one synthetic pair per rank:
+two 4096x4096x3 f32 frames -> 6144x4096x3 f32 mosaic (config 2 of BASELINE.json; for N>1 rank r takes pairs
+[r*K,(r+1)*K) of the config-4 family, p[3] = -2048 - 8i).  Frames are generated on the device before the timed
+region, so every input is resident in HBM when timing starts.  Pairs are independent: no data-path collective;
+for N>1 each finished mosaic is cast to unsigned char (the reference's own output type) and all-gathered
+(RCCL over xGMI) on the communicator's stream while the next pair computes, so that every rank ends up holding
+the whole batch -- that exchange is inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (largest share of device time), timed
+with HIP events on the launch stream inside the timed region; `pipeline` gives the same accounting for the whole
+pair.  `cpu_baseline` (N=1, rank 0) times the oracle's CPU restatement on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E nominal, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frame", type=int, default=4096, help="frame edge (4096 = the metric's configuration)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frame", type=int, default=4096, help="frame edge of the CPU baseline's bounded sample")
+    ap.add_argument("--no-kernel-events", action="store_true", help="time without per-launch HIP events")
+    ap.add_argument("--verbose", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_frame, verbose=False):
+    """The oracle (CPU restatement proven bit-identical to the reference, kind 'port') on one f32 pair of
+    sample_frame^2 frames -> 1.5*sample_frame x sample_frame canvas, same map family; single thread and all cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from oracle_lib import Oracle
+    from computervisionimagestich2_amd import pipeline
+    O = Oracle()
+    S = sample_frame
+    cw, ch = pipeline.config_canvas(S)
+    A, B = O.synth(S, S, 0, np.float32), O.synth(S, S, 1, np.float32)
+    p = pipeline.config_map(0, S)
+    # threads this process may actually run on (the GPU box grants a share of the host's cores)
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, int(os.environ.get("STITCH_CPU_THREADS", "16"))))
+    res = {}
+    for thr in sorted({1, ncores}):
+        O.set_threads(thr)
+        t = time.time()
+        rc, _ = O.pair(B, p, 0.0, 0.0, A, 0, 0, cw, ch)
+        dt = time.time() - t
+        assert rc == 0
+        res[thr] = cw * ch / dt / 1e6
+        if verbose:
+            print(f"[cpu_baseline] {thr} thread(s): {dt:.2f} s -> {res[thr]:.3f} MPix/s", file=sys.stderr)
+    best = max(res, key=lambda k: res[k])
+    return {"value": round(res[best], 4), "unit": "MPix/s", "cores": best, "kind": "port",
+            "sample": f"one {S}x{S}x3 f32 pair -> {cw}x{ch} canvas (oracle/stitch_oracle.c, OpenMP over lines)",
+            "single_thread_value": round(res[1], 4), "host_cores": ncores}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from computervisionimagestich2_amd import capi, pipeline
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    F = args.frame
+    cw, ch = pipeline.config_canvas(F)
+    K, W = args.steps, args.warmup
+    plan = capi.Plan(cw, ch)
+
+    # inputs: pair i of this rank = frames (2i, 2i+1), map p[3] = -F/2 - 8i; resident before timing starts
+    n_distinct = min(K + W, 8)
+    first = rank * K
+    pairs = []
+    for j in range(n_distinct):
+        i = (first + j) % 32
+        pairs.append((capi.dev_synth(F, F, 2 * i, torch.float32, dev), capi.dev_synth(F, F, 2 * i + 1, torch.float32, dev),
+                      pipeline.config_map(i, F)))
+    outs = [torch.empty((3, ch, cw), dtype=torch.float32, device=dev) for _ in range(2)]
+    if world > 1:
+        q8 = [torch.empty((3, ch, cw), dtype=torch.uint8, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world, 3, ch, cw), dtype=torch.uint8, device=dev) for _ in range(2)]
+    works = [None, None]
+
+    def step(k):
+        A, B, p = pairs[k % n_distinct]
+        out = outs[k % 2]
+        plan.pair(B, p, 0.0, 0.0, A, 0, 0, out)
+        if world > 1:
+            if works[k % 2] is not None:
+                works[k % 2].wait()  # the gather that last used this slot must be done before it is overwritten
+            capi.dev_quantize(out, q8[k % 2])
+            works[k % 2] = dist.all_gather_into_tensor(gathered[k % 2], q8[k % 2], async_op=True)
+
+    def drain():
+        for wk in works:
+            if wk is not None:
+                wk.wait()
+        torch.cuda.synchronize()
+
+    for k in range(W):
+        step(k)
+    drain()
+    plan.status()  # raises if the seam scan failed
+    plan.set_profiling(not args.no_kernel_events)
+    plan.read_profile()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(W + k)
+    drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = plan.read_profile()
+    plan.set_profiling(False)
+    seam = plan.status()
+
+    if rank == 0:
+        mpix_pair = cw * ch / 1e6
+        value = mpix_pair * K * world / elapsed
+        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, 4)
+        line = {
+            "metric": "warp+blend MPix/s at 4096x4096x3 f32", "value": round(value, 2), "unit": "MPix/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 accumulators)",
+            "data": "synthetic",
+            "config": {"workload": f"config 2: one {F}x{F}x3 f32 pair per GPU per step -> {cw}x{ch}x3 f32 mosaic "
+                                   f"(warp + move + {plan.levels}-level multi-band blend), canvas pixels counted",
+                       "frame": [F, F, 3], "canvas": [cw, ch, 3], "levels": plan.levels,
+                       "pairs_per_step": world, "mpix_per_pair": round(mpix_pair, 3),
+                       "input_frame_mpix_per_s": round(2 * F * F / 1e6 * K * world / elapsed, 2),
+                       "exchange": "none" if world == 1 else "uint8 mosaics all-gathered (RCCL) overlapped with compute",
+                       "seam": list(seam.as_tuple())},
+        }
+        tot_ms = sum(v[0] for v in prof.values())
+        if tot_ms > 0:
+            dom = max(prof, key=lambda k_: prof[k_][0])
+            ms, launches, _ = prof[dom]
+            bytes_per_launch = per_kernel[dom] * K / launches  # K pairs were profiled
+            avg_s = ms / launches / 1e3
+            achieved = bytes_per_launch / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            line["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                "avg_launch_ms": round(ms / launches, 5), "launches": launches,
+                                "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                                "share_of_device_time": round(ms / tot_ms, 4)}
+            line["kernels"] = {k_: {"ms_per_pair": round(v[0] / K, 4), "launches_per_pair": v[1] // K,
+                                    "level0_ms_per_pair": round(v[2] / K, 4),
+                                    "algorithmic_GBps": round(per_kernel[k_] / (v[0] / K / 1e3) / 1e9, 1) if v[0] > 0 else None}
+                               for k_, v in prof.items()}
+        pair_s = elapsed / K
+        line["pipeline"] = {"algorithmic_bytes_per_pair": stages["total"], "S1": stages["S1"], "S2": stages["S2"], "S3": stages["S3"],
+                            "achieved_GBps_per_gpu": round(stages["total"] / pair_s / 1e9, 1),
+                            "frac_of_hbm_peak": round(stages["total"] / pair_s / 1e9 / HBM_PEAK_GBS, 4),
+                            "device_ms_per_pair_sum_of_kernels": round(tot_ms / K, 4) if tot_ms > 0 else None}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_frame, args.verbose)
+        print(json.dumps(line), flush=True)
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

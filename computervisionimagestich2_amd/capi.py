@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstitch_hip.so")
 
-STAGES = ("compose", "blur_x", "blur_y", "decimate", "collapse")
+KERNELS = ("compose", "seam_mask", "vv_x_fwd", "vv_x_bwd", "vv_y_fwd", "vv_y_bwd", "decimate", "collapse")
 
 
 class StitchError(RuntimeError):
@@ -269,6 +269,23 @@ def dev_finish(result, num=19.0, den=20.0, hist=None):
     return result
 
 
+def dev_synth(w, h, frame_id, dtype, device=None):
+    """Synthetic benchmark frame generated on the device -> (3,h,w) tensor."""
+    import torch
+    out = torch.empty((3, h, w), dtype=dtype, device=device or torch.device("cuda", torch.cuda.current_device()))
+    _chk(getattr(lib(), "stitch_dev_synth_" + _tsfx(out))(_dp(out), int(w), int(h), int(frame_id), _stream()))
+    return out
+
+
+def dev_quantize(src, out=None):
+    """float mosaic -> unsigned char by truncation (CImg.h:11167-11182, behind ImageProcess.cpp:772)."""
+    import torch
+    assert src.is_cuda and src.is_contiguous() and src.dtype == torch.float32
+    out = torch.empty(src.shape, dtype=torch.uint8, device=src.device) if out is None else out
+    _chk(lib().stitch_dev_quantize_u8(_dp(src), _dp(out), C.c_size_t(src.numel()), _stream()))
+    return out
+
+
 class Plan:
     """stitch_plan: the device workspace of one canvas size (pyramids, scratch, tables, seam record)."""
 
@@ -329,9 +346,9 @@ class Plan:
         _chk(lib().stitch_plan_set_profiling(self._h, int(bool(on))))
 
     def read_profile(self):
-        """-> {stage: (total_ms, launches, level0_ms)} since profiling was enabled / last read."""
-        ms = (C.c_double * len(STAGES))()
-        n = (C.c_int * len(STAGES))()
-        l0 = (C.c_double * len(STAGES))()
+        """-> {kernel: (total_ms, launches, level0_ms)} since profiling was enabled / last read."""
+        ms = (C.c_double * len(KERNELS))()
+        n = (C.c_int * len(KERNELS))()
+        l0 = (C.c_double * len(KERNELS))()
         _chk(lib().stitch_plan_read_profile(self._h, ms, n, l0))
-        return {STAGES[i]: (ms[i], n[i], l0[i]) for i in range(len(STAGES))}
+        return {KERNELS[i]: (ms[i], n[i], l0[i]) for i in range(len(KERNELS))}

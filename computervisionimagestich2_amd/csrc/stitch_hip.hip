@@ -238,35 +238,43 @@ int run_reduce(stitch_plan* p, hipStream_t s) {
         const long lines = 7L * a.h;
         const bool do_x = a.w > 1 && !p->blur_skip, do_y = a.h > 1 && !p->blur_skip;
         if (p->opts.blur_kind == 0) {
-            {
-                StageTimer t(p, s, STITCH_STAGE_BLUR_X, l);
-                if (do_x) {
-                    const int nb = (int)((lines + TS - 1) / TS);
+            if (do_x) {
+                const int nb = (int)((lines + TS - 1) / TS);
+                {
+                    StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
                     k_vv_x_fwd<<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state);
+                }
+                {
+                    StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
                     k_vv_x_bwd<<<nb, 64, 0, s>>>(p->T, a.w, a.pitch, lines, p->vvk, p->state);
-                } else
-                    HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * 7, hipMemcpyDeviceToDevice, s));
-            }
+                }
+            } else
+                HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * 7, hipMemcpyDeviceToDevice, s));
             if (do_y) {
-                StageTimer t(p, s, STITCH_STAGE_BLUR_Y, l);
                 dim3 g(a.pitch / 64, 7);
-                k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
-                k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
+                {
+                    StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
+                    k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
+                }
+                {
+                    StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
+                    k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
+                }
             }
         } else {
             HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * 7, hipMemcpyDeviceToDevice, s));
             if (do_x) {
-                StageTimer t(p, s, STITCH_STAGE_BLUR_X, l);
+                StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
                 k_deriche<<<(int)((lines + 63) / 64), 64, 0, s>>>(p->T, p->T2, a.w, 1, a.pitch, a.h, a.ps, lines, p->drk);
             }
             if (do_y) {
-                StageTimer t(p, s, STITCH_STAGE_BLUR_Y, l);
+                StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
                 const long cols = 7L * a.w;
                 k_deriche<<<(int)((cols + 63) / 64), 64, 0, s>>>(p->T, p->T2, a.h, a.pitch, 1, a.w, a.ps, cols, p->drk);
             }
         }
         {
-            StageTimer t(p, s, STITCH_STAGE_DECIMATE, l);
+            StageTimer t(p, s, STITCH_K_DECIMATE, l);
             k_decimate<<<grid_xy(b.pitch, b.h, 7), 256, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, b.g, b.w, b.h, b.pitch, b.ps);
         }
     }
@@ -278,14 +286,14 @@ int run_collapse(stitch_plan* p, OUT* d_out, hipStream_t s) {
     const int L = p->L;
     {
         const Level& t = p->lv[L - 1];
-        StageTimer tm(p, s, STITCH_STAGE_COLLAPSE, L - 1);
+        StageTimer tm(p, s, STITCH_K_COLLAPSE, L - 1);
         k_blend_top<<<grid_xy(t.pitch, t.h), 256, 0, s>>>(t.g, t.pitch, t.h, t.ps, t.e);
         if (L == 1) k_emit_top<OUT><<<grid_xy(t.w, t.h), 256, 0, s>>>(t.e, t.w, t.h, t.pitch, t.ps, d_out);
     }
     for (int l = L - 2; l >= 0; --l) {
         const Level& a = p->lv[l];
         const Level& n = p->lv[l + 1];
-        StageTimer tm(p, s, STITCH_STAGE_COLLAPSE, l);
+        StageTimer tm(p, s, STITCH_K_COLLAPSE, l);
         ExpandTab tb{a.ix, a.ax, a.iy, a.ay};
         if (l == 0)
             k_collapse<OUT, true><<<grid_xy(a.w, a.h), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, n.g, n.e, n.w, n.h, n.pitch,
@@ -299,6 +307,7 @@ int run_collapse(stitch_plan* p, OUT* d_out, hipStream_t s) {
 
 int run_seam_mask(stitch_plan* p, hipStream_t s) {
     const Level& a = p->lv[0];
+    StageTimer t(p, s, STITCH_K_SEAM_MASK, 0);
     k_seam<<<1, 1024, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam);
     k_mask<<<grid_xy(a.pitch, a.h), 256, 0, s>>>(a.g + 6 * a.ps, a.w, a.pitch, p->d_seam);
     HIPCHK(hipMemcpyAsync(p->h_seam, p->d_seam, sizeof(SeamDev), hipMemcpyDeviceToHost, s));
@@ -320,10 +329,10 @@ int dev_blend(stitch_plan* p, const PX* d_a, const PX* d_b, PX* d_out, void* str
     hipStream_t s = as_stream(stream);
     const Level& a = p->lv[0];
     {
-        StageTimer t(p, s, STITCH_STAGE_COMPOSE, 0);
+        StageTimer t(p, s, STITCH_K_COMPOSE, 0);
         k_load_canvases<PX><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(d_a, d_b, a.g, a.w, a.h, a.pitch, a.ps);
-        if ((rc = run_seam_mask(p, s))) return rc;
     }
+    if ((rc = run_seam_mask(p, s))) return rc;
     if ((rc = run_reduce(p, s))) return rc;
     if ((rc = run_collapse<PX>(p, d_out, s))) return rc;
     p->last_stream = s;
@@ -342,11 +351,11 @@ int dev_pair(stitch_plan* p, const PX* d_frame, int fw, int fh, const double pm[
     MapP m;
     std::memcpy(m.p, pm, sizeof m.p);
     {
-        StageTimer t(p, s, STITCH_STAGE_COMPOSE, 0);
+        StageTimer t(p, s, STITCH_K_COMPOSE, 0);
         k_compose<PX><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(d_frame, fw, fh, m, offx, offy, d_mosaic, mw, mh, ox, oy, a.g, a.w,
                                                            a.h, a.pitch, a.ps);
-        if ((rc = run_seam_mask(p, s))) return rc;
     }
+    if ((rc = run_seam_mask(p, s))) return rc;
     if ((rc = run_reduce(p, s))) return rc;
     if ((rc = run_collapse<PX>(p, d_out, s))) return rc;
     p->last_stream = s;
@@ -822,14 +831,14 @@ int stitch_plan_set_profiling(stitch_plan* p, int enabled) {
     return STITCH_OK;
 }
 
-int stitch_plan_read_profile(stitch_plan* p, double stage_ms[STITCH_STAGE_COUNT], int stage_launches[STITCH_STAGE_COUNT],
-                             double level0_ms[STITCH_STAGE_COUNT]) {
+int stitch_plan_read_profile(stitch_plan* p, double stage_ms[STITCH_K_COUNT], int stage_launches[STITCH_K_COUNT],
+                             double level0_ms[STITCH_K_COUNT]) {
     if (!p) return fail(STITCH_ERR_ARG, "null plan");
     if (p->pending) {
         HIPCHK(hipStreamSynchronize(p->last_stream));
         p->pending = false;
     }
-    for (int i = 0; i < STITCH_STAGE_COUNT; ++i) {
+    for (int i = 0; i < STITCH_K_COUNT; ++i) {
         if (stage_ms) stage_ms[i] = 0;
         if (stage_launches) stage_launches[i] = 0;
         if (level0_ms) level0_ms[i] = 0;
@@ -862,6 +871,28 @@ int stitch_dev_lummix_u8(uint8_t* d_result, const uint8_t* d_equalized, int w, i
 
 int stitch_dev_finish_u8(uint8_t* d_result, int w, int h, double num, double den, int32_t* d_hist256, void* stream) {
     return dev_equalize_impl(d_result, w, h, d_hist256, true, num, den, stream);
+}
+
+int stitch_dev_synth_u8(uint8_t* d_dst, int w, int h, int frame_id, void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_dst || w <= 0 || h <= 0 || w >= (1 << 18) || h >= (1 << 18)) return fail(STITCH_ERR_ARG, "synth: bad argument");
+    k_synth<uint8_t><<<grid_xy(w, h, 3), 256, 0, as_stream(stream)>>>(d_dst, w, h, frame_id);
+    return launch_check("k_synth");
+}
+int stitch_dev_synth_f32(float* d_dst, int w, int h, int frame_id, void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_dst || w <= 0 || h <= 0 || w >= (1 << 18) || h >= (1 << 18)) return fail(STITCH_ERR_ARG, "synth: bad argument");
+    k_synth<float><<<grid_xy(w, h, 3), 256, 0, as_stream(stream)>>>(d_dst, w, h, frame_id);
+    return launch_check("k_synth");
+}
+int stitch_dev_quantize_u8(const float* d_src, uint8_t* d_dst, size_t n, void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_src || !d_dst || n == 0) return fail(STITCH_ERR_ARG, "quantize: bad argument");
+    k_quantize<<<eq_grid((n + 3) / 4), 256, 0, as_stream(stream)>>>(d_src, d_dst, n);
+    return launch_check("k_quantize");
 }
 
 }  // extern "C"

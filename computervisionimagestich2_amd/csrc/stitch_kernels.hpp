@@ -829,4 +829,44 @@ __global__ __launch_bounds__(256) void k_lummix(uint8_t* __restrict__ res, const
     }
 }
 
+// ---- synthetic frames and the CImg<uchar>(CImg<float>) cast ---------------------------------
+// v = 1 + ((3x + 5y + 37c + 101f) mod 200) + (splitmix64(seed ^ key) mod 50), never 0; the float twin adds
+// frac = ((hash >> 32) & 0xFFFF) / 65536.  Deterministic, so every rank and the CPU baseline see the same frames.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+template <typename PX>
+__global__ __launch_bounds__(256) void k_synth(PX* __restrict__ dst, int w, int h, int f) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
+    if (x >= w) return;
+    const uint64_t key = ((uint64_t)f << 40) | ((uint64_t)c << 36) | ((uint64_t)y << 18) | (uint64_t)x;
+    const uint64_t hsh = splitmix64(0x5717C4EDULL ^ key);
+    const int v = 1 + (int)((3LL * x + 5LL * y + 37LL * c + 101LL * f) % 200) + (int)(hsh % 50);
+    float out = (float)v;
+    if (sizeof(PX) == 4) out += (float)((hsh >> 32) & 0xFFFF) / 65536.0f;
+    dst[(size_t)c * w * h + (size_t)y * w + x] = px_store<PX>(out);
+}
+
+// float -> unsigned char by C-cast truncation: what `return expand;` does at ImageProcess.cpp:772 through
+// CImg<unsigned char>(const CImg<float>&) (CImg.h:11167-11182).  Values are in [0,255] after the collapse clamp.
+__global__ __launch_bounds__(256) void k_quantize(const float* __restrict__ src, uint8_t* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n && ((reinterpret_cast<uintptr_t>(src + i) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst + i) & 3) == 0)) {
+            const f4 v = *reinterpret_cast<const f4*>(src + i);
+            uchar4 o;
+            o.x = (uint8_t)(int)v.x;
+            o.y = (uint8_t)(int)v.y;
+            o.z = (uint8_t)(int)v.z;
+            o.w = (uint8_t)(int)v.w;
+            *reinterpret_cast<uchar4*>(dst + i) = o;
+        } else {
+            for (size_t j = i; j < n && j < i + 4; ++j) dst[j] = (uint8_t)(int)src[j];
+        }
+    }
+}
+
 }  // namespace sk

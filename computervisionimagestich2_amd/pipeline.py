@@ -1,0 +1,95 @@
+"""Host-side drivers above the C ABI: the benchmark configurations of BASELINE.json, the panorama chain of
+ImageProcess::matching (ImageProcess.cpp:159-268, hot-path calls only), and the sharding of independent pairs
+across the GPUs of a node (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI).
+
+Nothing here computes pixels: every per-pixel operation is a HIP kernel reached through capi.
+"""
+import math
+
+from . import capi
+
+SEED_MAP = (1.0, 0.002, 1e-6, -2048.0, -0.001, 1.0, 5e-7, 1.5)  # config-2 backward map, SURVEY.md 8(d)
+
+
+def config_map(pair_index=0, frame=4096):
+    """Backward map of synthetic pair `pair_index`: p[3] = -(frame/2) - 8*i so that pairs differ (config 4)."""
+    p = list(SEED_MAP)
+    p[3] = -(frame / 2.0) - 8.0 * pair_index
+    return p
+
+
+def config_canvas(frame=4096):
+    """Canvas of the synthetic pair configs: fixed by definition at 1.5*frame x frame (6144x4096 for config 2)."""
+    return frame * 3 // 2, frame
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items for `rank` (config 4: 32 pairs -> 4 per GPU on 8 ranks)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample=4):
+    """SURVEY.md 8(d) byte accounting for one pair: every distinct input array read once + every output array
+    written once, pyramid planes f32.  Returns per-kernel bytes (this implementation's kernels, each with its own
+    inputs/outputs counted once) and the canonical stage totals S1..S3 the headline fraction uses."""
+    n = [w * h for w, h in zip(level_w, level_h)]
+    L = len(n)
+    P = n[0]
+    s1 = (frame_px_a + frame_px_b) * 3 * bytes_per_sample + 2 * P * 3 * 4
+    s2 = sum(7 * 4 * (3 * n[l] + n[l + 1]) for l in range(L - 1))
+    s3 = sum(4 * (10 * n[l] + 9 * n[l + 1]) for l in range(L - 1)) + 4 * 10 * n[L - 1]
+    line = sum(2 * 7 * 4 * n[l] for l in range(L - 1))  # one recursive pass: read 7 planes, write 7 planes
+    per_kernel = {
+        "compose": s1,
+        "seam_mask": 4 * P,  # mask step written once (the two mid rows read are negligible)
+        "vv_x_fwd": line, "vv_x_bwd": line, "vv_y_fwd": line, "vv_y_bwd": line,
+        "decimate": sum(7 * 4 * (n[l] + n[l + 1]) for l in range(L - 1)),
+        "collapse": s3,
+    }
+    return per_kernel, {"S1": s1, "S2": s2, "S3": s3, "total": s1 + s2 + s3}
+
+
+class PairStitcher:
+    """warp + move + blend of independent pairs on one GPU with a workspace allocated once (stitch_plan)."""
+
+    def __init__(self, cw, ch, opts=None):
+        self.plan = capi.Plan(cw, ch, opts)
+        self.cw, self.ch = cw, ch
+
+    def run(self, frame, p, mosaic, out=None, offx=0.0, offy=0.0, ox=0, oy=0):
+        return self.plan.pair(frame, p, offx, offy, mosaic, ox, oy, out)
+
+    def close(self):
+        self.plan.close()
+
+
+def stitch_chain(frames, steps, opts=None, finish=True, num=19.0, den=20.0):
+    """The hot-path calls of ImageProcess::matching for a recorded stitch order, device resident.
+
+    frames: list of (3,H,W) uint8 device tensors (unprojected).  steps: list of dicts with keys
+    src (index of the frame to warp), p (8 doubles), offx, offy, ox, oy, cw, ch -- what the reference passes at
+    ImageProcess.cpp:218-230; the first mosaic is projection(frames[start]).
+    Returns the final uint8 mosaic tensor (after equalisation + luminance mix when finish=True, :237-268)."""
+    proj = {}
+
+    def projected(i):
+        if i not in proj:
+            proj[i] = capi.dev_project(frames[i])
+        return proj[i]
+
+    result = projected(steps[0]["start"])
+    for st in steps:
+        plan = capi.Plan(st["cw"], st["ch"], opts)
+        result = plan.pair(projected(st["src"]), st["p"], st["offx"], st["offy"], result, st["ox"], st["oy"])
+        plan.status()
+        plan.close()
+    if finish:
+        capi.dev_finish(result, num, den)
+    return result
+
+
+def levels_of(cw, ch, level_rule=0):
+    length = min(cw, ch) if level_rule else max(cw, ch)
+    return int(math.floor(math.log2(length)))

@@ -140,25 +140,37 @@ int stitch_dev_pair_f32(stitch_plan *plan, const float *d_frame, int fw, int fh,
  * STITCH_ERR_ZERO_OVERLAP (in the error cases the output buffer holds unspecified finite values). */
 int stitch_plan_status(stitch_plan *plan, stitch_seam *seam_out);
 
-/* Per-stage device timing of a plan's calls, with HIP events on the call's stream.  Stage ids: */
+/* Per-kernel device timing of a plan's calls, with HIP events recorded on the call's stream around every
+ * launch.  Kernel ids: */
 enum {
-    STITCH_STAGE_COMPOSE = 0, /* warp + move (+ value cast) -> level-0 planes, seam scan, mask step             */
-    STITCH_STAGE_BLUR_X = 1,  /* recursive Gaussian along rows, all levels                                       */
-    STITCH_STAGE_BLUR_Y = 2,  /* recursive Gaussian along columns, all levels                                    */
-    STITCH_STAGE_DECIMATE = 3,/* moving-average halving, all levels                                              */
-    STITCH_STAGE_COLLAPSE = 4,/* expand + Laplacian + per-level blend + collapse, all levels                     */
-    STITCH_STAGE_COUNT = 5
+    STITCH_K_COMPOSE = 0,   /* k_compose / k_load_canvases: warp + move + value cast -> level-0 planes            */
+    STITCH_K_SEAM_MASK = 1, /* k_seam + k_mask: mid-row scan, mask step                                           */
+    STITCH_K_VV_X_FWD = 2,  /* recursive Gaussian along rows, causal pass (Deriche: whole x pass)                 */
+    STITCH_K_VV_X_BWD = 3,  /* recursive Gaussian along rows, anticausal pass                                     */
+    STITCH_K_VV_Y_FWD = 4,  /* recursive Gaussian along columns, causal pass (Deriche: whole y pass)              */
+    STITCH_K_VV_Y_BWD = 5,  /* recursive Gaussian along columns, anticausal pass                                  */
+    STITCH_K_DECIMATE = 6,  /* moving-average halving                                                             */
+    STITCH_K_COLLAPSE = 7,  /* expand + Laplacian + per-level blend + collapse (and the top-level blend)          */
+    STITCH_K_COUNT = 8
 };
 int stitch_plan_set_profiling(stitch_plan *plan, int enabled);
-/* Sums (ms) and launch counts per stage since profiling was enabled or last read; synchronises the stream.
- * level0_ms[stage] = the share of the finest level alone (the dominant launch of each stage). */
-int stitch_plan_read_profile(stitch_plan *plan, double stage_ms[STITCH_STAGE_COUNT],
-                             int stage_launches[STITCH_STAGE_COUNT], double level0_ms[STITCH_STAGE_COUNT]);
+/* Sums since profiling was enabled or last read; synchronises the plan's stream.  total_ms[k] / launches[k] is
+ * the average launch duration of kernel k over all pyramid levels; level0_ms[k] is the finest level's share. */
+int stitch_plan_read_profile(stitch_plan *plan, double total_ms[STITCH_K_COUNT], int launches[STITCH_K_COUNT],
+                             double level0_ms[STITCH_K_COUNT]);
 
 int stitch_dev_equalize_u8(uint8_t *d_img, int w, int h, int32_t *d_hist256, void *stream);
 int stitch_dev_lummix_u8(uint8_t *d_result, const uint8_t *d_equalized, int w, int h, double num, double den,
                          void *stream);
 int stitch_dev_finish_u8(uint8_t *d_result, int w, int h, double num, double den, int32_t *d_hist256, void *stream);
+
+/* Deterministic synthetic frames of the benchmark configs: values 1..250, never 0 ("empty" to
+ * the seam scan); the float twin adds a 16-bit fraction.  Same generator as oracle_synth_* (tests compare). */
+int stitch_dev_synth_u8(uint8_t *d_dst, int w, int h, int frame_id, void *stream);
+int stitch_dev_synth_f32(float *d_dst, int w, int h, int frame_id, void *stream);
+/* CImg<unsigned char>(const CImg<float>&) (CImg.h:11167-11182), the cast behind `return expand;`
+ * (ImageProcess.cpp:772): the uchar mosaic of a float-frame pair, e.g. for the all-gather of finished mosaics. */
+int stitch_dev_quantize_u8(const float *d_src, uint8_t *d_dst, size_t n, void *stream);
 
 #ifdef __cplusplus
 }
