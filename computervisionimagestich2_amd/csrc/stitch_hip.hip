@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -188,6 +189,7 @@ struct stitch_plan {
     VVK vvk{};
     DRK drk{};
     bool blur_skip = false;
+    bool no_fuse = false;  // STITCH_NO_FUSE=1: keep blur and decimation as separate kernels (A/B and tests)
     bool profiling = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> free_events;
@@ -237,6 +239,7 @@ int run_reduce(stitch_plan* p, hipStream_t s) {
         const Level& b = p->lv[l + 1];
         const long lines = 7L * a.h;
         const bool do_x = a.w > 1 && !p->blur_skip, do_y = a.h > 1 && !p->blur_skip;
+        bool decimated = false;
         if (p->opts.blur_kind == 0) {
             if (do_x) {
                 const int nb = (int)((lines + TS - 1) / TS);
@@ -256,10 +259,12 @@ int run_reduce(stitch_plan* p, hipStream_t s) {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
                     k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
                 }
-                {
-                    StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
+                StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
+                if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
+                    k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
+                    decimated = true;
+                } else
                     k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
-                }
             }
         } else {
             HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * 7, hipMemcpyDeviceToDevice, s));
@@ -273,7 +278,7 @@ int run_reduce(stitch_plan* p, hipStream_t s) {
                 k_deriche<<<(int)((cols + 63) / 64), 64, 0, s>>>(p->T, p->T2, a.h, a.pitch, 1, a.w, a.ps, cols, p->drk);
             }
         }
-        {
+        if (!decimated) {
             StageTimer t(p, s, STITCH_K_DECIMATE, l);
             k_decimate<<<grid_xy(b.pitch, b.h, 7), 256, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, b.g, b.w, b.h, b.pitch, b.ps);
         }
@@ -691,6 +696,7 @@ int stitch_plan_create(int cw, int ch, const stitch_blend_opts* opts, stitch_pla
     p->opts = o;
     p->vvk = make_vvk(o.sigma);
     p->drk = make_drk(o.sigma);
+    p->no_fuse = std::getenv("STITCH_NO_FUSE") != nullptr;
     p->blur_skip = o.blur_kind == 0 ? (o.sigma < 0.5f) : (o.sigma < 0.1f);  // CImg.h:35051 / :34800
     if (hipGetDevice(&p->device) != hipSuccess) {
         delete p;

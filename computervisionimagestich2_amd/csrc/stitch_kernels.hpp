@@ -462,9 +462,75 @@ __global__ __launch_bounds__(64) void k_vv_x_bwd(float* __restrict__ data, int w
     }
 }
 
+// overlap weights of the moving-average resize (used by the fused anticausal pass and by k_decimate)
+struct Taps {  // up to 4 overlaps per output sample (3 when n_src = 2*n_dst+1, 2 when n_src = 2*n_dst)
+    int s0, n;
+    float d[4];
+};
+__device__ __forceinline__ Taps make_taps(int t, int n_src, int n_dst) {
+    Taps r;
+    const long long pos = (long long)t * n_src;
+    int s = (int)(pos / n_dst);
+    int c_left = (int)((long long)(s + 1) * n_dst - pos);
+    int remaining = n_src;
+    r.s0 = s;
+    r.n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = remaining < c_left ? remaining : c_left;
+        r.d[i] = (float)(unsigned)d;
+        if (d > 0) r.n = i + 1;
+        remaining -= d;
+        c_left = n_dst;
+    }
+    return r;
+}
+
 // y pass: one column per work-item, so a wavefront reads/writes 256 contiguous bytes of one row per step.
-// Rows are fetched UY at a time ahead of the recurrence.  In place.  grid = (pitch/64, planes).
-constexpr int UY = 8;
+// The recurrence is cheap next to an HBM round trip, so rows are fetched far ahead of their use: YST stages of
+// YCH rows rotate through registers (YCH*(YST-1) = 24 rows in flight per wavefront while one chunk computes).
+// In place.  grid = (pitch/64, planes).
+constexpr int YCH = 8, YST = 4;
+
+// Calls f(y, value) for rows y_begin, y_begin +/- 1, ... (count rows), loading each row's value long before.
+template <bool DOWN, typename F>
+__device__ __forceinline__ void stream_rows(const float* __restrict__ p, int pitch, int y_begin, int count, F&& f) {
+    float buf[YST][YCH];
+    // row index is clamped instead of predicated: the tail re-reads the last row, the loop body stays branch-free
+    auto ld = [&](int i) {
+        const int ic = i < count ? i : count - 1;
+        return p[(size_t)(DOWN ? y_begin + ic : y_begin - ic) * pitch];
+    };
+#pragma unroll
+    for (int s = 0; s < YST - 1; ++s)
+#pragma unroll
+        for (int u = 0; u < YCH; ++u) buf[s][u] = ld(s * YCH + u);
+    int c0 = 0;
+    for (; c0 + YST * YCH <= count; c0 += YST * YCH) {  // whole groups: no predicates at all
+#pragma unroll
+        for (int s = 0; s < YST; ++s) {
+#pragma unroll
+            for (int u = 0; u < YCH; ++u) buf[(s + YST - 1) % YST][u] = ld(c0 + (s + YST - 1) * YCH + u);
+#pragma unroll
+            for (int u = 0; u < YCH; ++u) {
+                const int i = c0 + s * YCH + u;
+                f(DOWN ? y_begin + i : y_begin - i, buf[s][u]);
+            }
+        }
+    }
+    if (c0 < count) {  // ragged last group
+#pragma unroll
+        for (int s = 0; s < YST; ++s) {
+#pragma unroll
+            for (int u = 0; u < YCH; ++u) buf[(s + YST - 1) % YST][u] = ld(c0 + (s + YST - 1) * YCH + u);
+#pragma unroll
+            for (int u = 0; u < YCH; ++u) {
+                const int i = c0 + s * YCH + u;
+                if (i < count) f(DOWN ? y_begin + i : y_begin - i, buf[s][u]);
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(64) void k_vv_y_fwd(float* __restrict__ data, int h, int pitch, size_t ps, VVK k,
                                                   double* __restrict__ state) {
@@ -473,28 +539,16 @@ __global__ __launch_bounds__(64) void k_vv_y_fwd(float* __restrict__ data, int h
     const double iplus = (double)p[(size_t)(h - 1) * pitch];
     double v1, v2, v3;
     v1 = v2 = v3 = (double)p[0] / k.sumsq;
-    float cur[UY], nxt[UY];
-#pragma unroll
-    for (int u = 0; u < UY; ++u) cur[u] = u < h ? p[(size_t)u * pitch] : 0.f;
-    for (int y0 = 0; y0 < h; y0 += UY) {
-#pragma unroll
-        for (int u = 0; u < UY; ++u) nxt[u] = (y0 + UY + u) < h ? p[(size_t)(y0 + UY + u) * pitch] : 0.f;
-#pragma unroll
-        for (int u = 0; u < UY; ++u) {
-            if (y0 + u < h) {
-                double v0 = (double)cur[u];
-                v0 += v1 * k.f1;
-                v0 += v2 * k.f2;
-                v0 += v3 * k.f3;
-                p[(size_t)(y0 + u) * pitch] = (float)v0;
-                v3 = v2;
-                v2 = v1;
-                v1 = v0;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UY; ++u) cur[u] = nxt[u];
-    }
+    stream_rows<true>(p, pitch, 0, h, [&](int y, float xv) {
+        double v0 = (double)xv;
+        v0 += v1 * k.f1;
+        v0 += v2 * k.f2;
+        v0 += v3 * k.f3;
+        p[(size_t)y * pitch] = (float)v0;
+        v3 = v2;
+        v2 = v1;
+        v1 = v0;
+    });
     const size_t n = (size_t)gridDim.x * WAVE * gridDim.y, i = (size_t)blockIdx.y * gridDim.x * WAVE + x;
     state[i] = v1;
     state[n + i] = v2;
@@ -502,6 +556,7 @@ __global__ __launch_bounds__(64) void k_vv_y_fwd(float* __restrict__ data, int h
     state[3 * n + i] = iplus;
 }
 
+// Anticausal y pass, stand-alone (odd source widths, Deriche-free fallback): stores the blurred rows in place.
 __global__ __launch_bounds__(64) void k_vv_y_bwd(float* __restrict__ data, int h, int pitch, size_t ps, VVK k,
                                                   const double* __restrict__ state) {
     const int x = blockIdx.x * WAVE + threadIdx.x;
@@ -512,30 +567,134 @@ __global__ __launch_bounds__(64) void k_vv_y_bwd(float* __restrict__ data, int h
     float first;
     triggs(k, iplus, v1, v2, v3, first);
     p[(size_t)(h - 1) * pitch] = first;
-    // remaining samples h-2 .. 0
-    float cur[UY], nxt[UY];
-    int top = h - 2;  // next sample to process
+    stream_rows<false>(p, pitch, h - 2, h - 1, [&](int y, float xv) {
+        double v0 = (double)xv;
+        v0 *= k.sum;
+        v0 += v1 * k.f1;
+        v0 += v2 * k.f2;
+        v0 += v3 * k.f3;
+        v3 = v2;
+        v2 = v1;
+        v1 = v0;
+        p[(size_t)y * pitch] = (float)v0;
+    });
+}
+
+// Anticausal y pass fused with the decimation (even source width): the blurred level is never written.
+// A lone wavefront is bound by its own instruction issue (recurrence + two IEEE divides per sample), so the
+// work is split over the two wavefronts of a workgroup:
+//   wave 0 (producer)  runs the recurrence for 64 columns, rows bottom-up, and drops each blurred row into an
+//                      LDS ring (two slots of YCH rows);
+//   wave 1 (consumer)  takes the rows two at a time -- lanes 0-31 own the 32 column pairs of the upper row,
+//                      lanes 32-63 those of the lower row -- x-decimates them (columns 2t, 2t+1, both overlaps
+//                      = w2, CImg.h:29542-29555: acc = 0; acc += s0*d; acc += s1*d; acc /= W), then lanes 0-31
+//                      y-decimate (CImg.h:29557-29575: accumulation in INCREASING source row although rows arrive
+//                      bottom-up; overlaps {h2,h2} for even h, {h2-t, h2, t+1} for odd h) and store 128 bytes
+//                      of the next pyramid level.
+// One workgroup barrier per YCH rows hands a slot over.  rc = h-1-y counts rows in processing order.
+__global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ data, int w, int h, int pitch, size_t ps,
+                                                      VVK k, const double* __restrict__ state, float* __restrict__ dst,
+                                                      int w2, int h2, int dpitch, size_t dps) {
+    __shared__ __attribute__((aligned(16))) float ring[2][YCH][WAVE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nchunks = (h + YCH - 1) / YCH;
+    // producer state
+    const int x = blockIdx.x * WAVE + lane;
+    const float* p = data + blockIdx.y * ps + x;
+    double v1 = 0, v2 = 0, v3 = 0;
+    float first = 0.f;
+    float buf[YST][YCH];
+    auto ld = [&](int rc) {
+        const int r = rc < h ? rc : h - 1;
+        return p[(size_t)(h - 1 - r) * pitch];
+    };
+    if (wave == 0) {
+        const size_t n = (size_t)gridDim.x * WAVE * gridDim.y, i = (size_t)blockIdx.y * gridDim.x * WAVE + x;
+        v1 = state[i];
+        v2 = state[n + i];
+        v3 = state[2 * n + i];
+        triggs(k, state[3 * n + i], v1, v2, v3, first);
 #pragma unroll
-    for (int u = 0; u < UY; ++u) cur[u] = (top - u) >= 0 ? p[(size_t)(top - u) * pitch] : 0.f;
-    for (; top >= 0; top -= UY) {
+        for (int s = 0; s < YST - 1; ++s)
 #pragma unroll
-        for (int u = 0; u < UY; ++u) nxt[u] = (top - UY - u) >= 0 ? p[(size_t)(top - UY - u) * pitch] : 0.f;
+            for (int u = 0; u < YCH; ++u) buf[s][u] = ld(s * YCH + u);
+    }
+    // consumer state
+    const float fsx = (float)(unsigned)w2, fw = (float)(unsigned)w, fh = (float)(unsigned)h, fsy = (float)(unsigned)h2;
+    const bool h_odd = (h & 1) != 0;
+    const int half = lane >> 5, cp = lane & 31;
+    float* drow = dst + blockIdx.y * dps + (blockIdx.x * (WAVE / 2) + cp);
+    const bool dst_live = half == 0 && (blockIdx.x * (WAVE / 2) + cp) < w2;
+    float pXlo = 0.f, pXhi = 0.f;  // previous pair (odd h only), valid in lanes 0-31
+
+    for (int j0 = 0; j0 <= nchunks; j0 += YST) {
 #pragma unroll
-        for (int u = 0; u < UY; ++u) {
-            if (top - u >= 0) {
-                double v0 = (double)cur[u];
-                v0 *= k.sum;
-                v0 += v1 * k.f1;
-                v0 += v2 * k.f2;
-                v0 += v3 * k.f3;
-                p[(size_t)(top - u) * pitch] = (float)v0;
-                v3 = v2;
-                v2 = v1;
-                v1 = v0;
+        for (int s = 0; s < YST; ++s) {
+            const int j = j0 + s;
+            if (wave == 0) {
+#pragma unroll
+                for (int u = 0; u < YCH; ++u) buf[(s + YST - 1) % YST][u] = ld((j + YST - 1) * YCH + u);
+                if (j < nchunks) {
+#pragma unroll
+                    for (int u = 0; u < YCH; ++u) {
+                        const int rc = j * YCH + u;
+                        float o;
+                        if (rc == 0) {
+                            o = first;  // sample h-1 takes the Triggs boundary value (CImg.h:34920)
+                        } else {
+                            double v0 = (double)buf[s][u];
+                            v0 *= k.sum;
+                            v0 += v1 * k.f1;
+                            v0 += v2 * k.f2;
+                            v0 += v3 * k.f3;
+                            v3 = v2;
+                            v2 = v1;
+                            v1 = v0;
+                            o = (float)v0;
+                        }
+                        ring[s & 1][u][lane] = o;  // rows rc >= h of the last chunk are never read
+                    }
+                }
+            } else if (j >= 1 && j - 1 < nchunks) {
+                const int jc = j - 1;
+#pragma unroll
+                for (int u = 0; u < YCH; u += 2) {
+                    const int rc_lo = jc * YCH + u;  // upper row of the pair (y = h-1-rc_lo), lower row is rc_lo+1
+                    if (rc_lo < h) {
+                        const float2 v = *reinterpret_cast<const float2*>(&ring[(s + 1) & 1][u + half][2 * cp]);
+                        float X = 0.f;
+                        X += v.x * fsx;
+                        X += v.y * fsx;
+                        X /= fw;
+                        const float Xhi = __shfl_down(X, 32, 64);  // lanes 0-31: lower row's pair
+                        const int m = rc_lo >> 1;
+                        if (!h_odd) {
+                            // rows (2t+1, 2t) with t = h2-1-m
+                            float a2 = 0.f;
+                            a2 += Xhi * fsy;
+                            a2 += X * fsy;
+                            a2 /= fh;
+                            if (dst_live) drow[(size_t)(h2 - 1 - m) * dpitch] = a2;
+                        } else {
+                            // pair m = rows (2*h2-2m, 2*h2-2m-1); output t = h2-m needs rows 2t (= this upper row),
+                            // 2t+1 and 2t+2 (= previous pair's lower and upper rows)
+                            if (m >= 1) {
+                                const int t = h2 - m;
+                                float a2 = 0.f;
+                                a2 += X * (float)(unsigned)(h2 - t);
+                                a2 += pXhi * fsy;
+                                a2 += pXlo * (float)(unsigned)(t + 1);
+                                a2 /= fh;
+                                if (dst_live) drow[(size_t)t * dpitch] = a2;
+                            }
+                            pXlo = X;
+                            pXhi = Xhi;
+                        }
+                    }
+                }
             }
+            __syncthreads();
         }
-#pragma unroll
-        for (int u = 0; u < UY; ++u) cur[u] = nxt[u];
     }
 }
 
@@ -578,29 +737,6 @@ __global__ __launch_bounds__(64) void k_deriche(float* __restrict__ data, float*
 // Output t of an axis accumulates, in increasing s, src[s]*(float)d into a float that starts at 0, where d is
 // the overlap of [t*n_src,(t+1)*n_src) with [s*n_dst,(s+1)*n_dst), then divides once by (float)n_src.  x first
 // (result rounded to float), then y -- both inside one work-item, which owns one output sample of one plane.
-struct Taps {  // up to 4 overlaps per output sample (3 when n_src = 2*n_dst+1, 2 when n_src = 2*n_dst)
-    int s0, n;
-    float d[4];
-};
-__device__ __forceinline__ Taps make_taps(int t, int n_src, int n_dst) {
-    Taps r;
-    const long long pos = (long long)t * n_src;
-    int s = (int)(pos / n_dst);
-    int c_left = (int)((long long)(s + 1) * n_dst - pos);
-    int remaining = n_src;
-    r.s0 = s;
-    r.n = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int d = remaining < c_left ? remaining : c_left;
-        r.d[i] = (float)(unsigned)d;
-        if (d > 0) r.n = i + 1;
-        remaining -= d;
-        c_left = n_dst;
-    }
-    return r;
-}
-
 __global__ __launch_bounds__(256) void k_decimate(const float* __restrict__ src, int w, int h, int spitch, size_t sps,
                                                   float* __restrict__ dst, int w2, int h2, int dpitch, size_t dps) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, pl = blockIdx.z;
