@@ -105,25 +105,21 @@ def main():
         pairs.append((capi.dev_synth(F, F, 2 * i, torch.float32, dev), capi.dev_synth(F, F, 2 * i + 1, torch.float32, dev),
                       pipeline.config_map(i, F)))
     outs = [torch.empty((3, ch, cw), dtype=torch.float32, device=dev) for _ in range(2)]
-    if world > 1:
-        q8 = [torch.empty((3, ch, cw), dtype=torch.uint8, device=dev) for _ in range(2)]
-        gathered = [torch.empty((world, 3, ch, cw), dtype=torch.uint8, device=dev) for _ in range(2)]
-    works = [None, None]
+    # N>1: finished mosaics travel as unsigned char (the reference's output type) through pipeline.MosaicGather --
+    # the class the gloo tests cover -- asynchronously, so the gather of pair k overlaps the kernels of pair k+1
+    gather = pipeline.MosaicGather((3, ch, cw), dev, world, rank, slots=2) if world > 1 else None
 
     def step(k):
         A, B, p = pairs[k % n_distinct]
         out = outs[k % 2]
         plan.pair(B, p, 0.0, 0.0, A, 0, 0, out)
-        if world > 1:
-            if works[k % 2] is not None:
-                works[k % 2].wait()  # the gather that last used this slot must be done before it is overwritten
-            capi.dev_quantize(out, q8[k % 2])
-            works[k % 2] = dist.all_gather_into_tensor(gathered[k % 2], q8[k % 2], async_op=True)
+        if gather is not None:
+            capi.dev_quantize(out, gather.input_slot(k))
+            gather.submit(k)
 
     def drain():
-        for wk in works:
-            if wk is not None:
-                wk.wait()
+        if gather is not None:
+            gather.drain()
         torch.cuda.synchronize()
 
     for k in range(W):

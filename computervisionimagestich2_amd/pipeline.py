@@ -93,3 +93,61 @@ def stitch_chain(frames, steps, opts=None, finish=True, num=19.0, den=20.0):
 def levels_of(cw, ch, level_rule=0):
     length = min(cw, ch) if level_rule else max(cw, ch)
     return int(math.floor(math.log2(length)))
+
+
+class MosaicGather:
+    """Assembles a sharded batch on every rank: each rank contributes one finished uint8 mosaic per step and the
+    step's mosaics of all ranks are all-gathered (torch.distributed: backend "nccl" = RCCL over xGMI on the GPUs;
+    "gloo" on CPU tensors in the tests).  The collective is asynchronous, so on the GPU it overlaps the next pair's
+    kernels; a ring of `slots` input/output buffers bounds memory.  With keep=True every step's gathered block is
+    retained (tests / small batches): result()[k, r] is the mosaic rank r produced at step k.
+
+    Pairs are independent, so this end-of-pair exchange is the only communication of the batch configs."""
+
+    def __init__(self, shape, device, world, rank, slots=2, keep=False, steps=0, group=None):
+        import torch
+        self.torch = torch
+        self.world, self.rank, self.slots, self.keep, self.group = world, rank, slots, keep, group
+        self.inp = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(slots)]
+        n_out = steps if keep else slots
+        self.out = [torch.empty((world,) + tuple(shape), dtype=torch.uint8, device=device) for _ in range(n_out)]
+        self.works = [None] * slots
+
+    def input_slot(self, k):
+        """Buffer to fill with step k's local mosaic; first waits for the gather that last used the slot."""
+        s = k % self.slots
+        if self.works[s] is not None:
+            self.works[s].wait()
+            self.works[s] = None
+        return self.inp[s]
+
+    def submit(self, k):
+        import torch.distributed as dist
+        s = k % self.slots
+        out = self.out[k if self.keep else s]
+        if self.world == 1:
+            out[0].copy_(self.inp[s])
+            return
+        # output viewed as the concatenation along dim 0 (the layout every backend accepts)
+        self.works[s] = dist.all_gather_into_tensor(out.flatten(0, 1), self.inp[s], group=self.group, async_op=True)
+
+    def drain(self):
+        for i, wk in enumerate(self.works):
+            if wk is not None:
+                wk.wait()
+                self.works[i] = None
+
+    def result(self):
+        assert self.keep
+        return self.torch.stack(self.out)
+
+
+def batch_order(n_pairs, world):
+    """(step, rank) -> global pair index for a batch sharded with shard_range (contiguous per rank), or None
+    where a rank has run out of pairs (ragged batches)."""
+    table = {}
+    for r in range(world):
+        lo, hi = shard_range(n_pairs, r, world)
+        for k in range(math.ceil(n_pairs / world)):
+            table[(k, r)] = lo + k if lo + k < hi else None
+    return table

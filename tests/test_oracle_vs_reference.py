@@ -1,0 +1,92 @@
+"""CPU, only where oracle/_ref/libref_hotpath.so exists (built from /root/reference by oracle/Makefile):
+the oracle against the reference's own functions on fresh seeded inputs.  Skipped on the GPU box when the
+prebuilt library did not travel."""
+import numpy as np
+import pytest
+
+from oracle_lib import Reference, have_reference
+
+pytestmark = pytest.mark.skipif(not have_reference(), reason="oracle/_ref/libref_hotpath.so not built (needs /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return Reference()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("w,h,f", [(384, 512, 1), (400, 300, 2), (97, 61, 3), (61, 97, 4), (2, 2, 5), (1, 9, 6), (9, 1, 7)])
+def test_project(oracle, ref, w, h, f):
+    src = oracle.synth(w, h, f)
+    assert np.array_equal(oracle.project(src), ref.project(src))
+
+
+def test_map_and_bbox(oracle, ref):
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        p = [1 + rng.normal() * 0.05, rng.normal() * 0.05, rng.normal() * 1e-4, rng.normal() * 300,
+             rng.normal() * 0.05, 1 + rng.normal() * 0.05, rng.normal() * 1e-5, rng.normal() * 20]
+        x, y = np.float32(rng.uniform(-500, 1500)), np.float32(rng.uniform(-500, 1500))
+        assert oracle.map_xy(x, y, p) == ref.map_xy(x, y, p)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_warp_move_random_maps(oracle, ref, seed):
+    rng = np.random.default_rng(seed)
+    src = oracle.synth(200, 150, seed)
+    p = [1 + rng.normal() * 0.03, rng.normal() * 0.03, rng.normal() * 1e-4, rng.normal() * 80,
+         rng.normal() * 0.03, 1 + rng.normal() * 0.03, rng.normal() * 1e-5, rng.normal() * 10]
+    offx, offy = np.float32(rng.uniform(-40, 0.99)), np.float32(rng.uniform(-9, 0.99))
+    assert np.array_equal(oracle.warp(src, p, offx, offy, 333, 177), ref.warp(src, p, offx, offy, 333, 177))
+    ox, oy = int(rng.integers(-50, 50)), int(rng.integers(-20, 20))
+    assert np.array_equal(oracle.move(src, ox, oy, 333, 177), ref.move(src, ox, oy, 333, 177))
+
+
+def test_warp_truncation_toward_zero(oracle, ref):
+    """coordinates in (-1,0) truncate to 0 and are therefore INSIDE the source (ImageProcess.cpp:598-600)"""
+    src = oracle.synth(40, 30, 1)
+    p = [1, 0, 0, -0.5, 0, 1, 0, -0.75]
+    a, b = oracle.warp(src, p, 0.0, 0.0, 50, 40), ref.warp(src, p, 0.0, 0.0, 50, 40)
+    assert np.array_equal(a, b) and a[0, 0, 0] == src[0, 0, 0]
+
+
+@pytest.mark.parametrize("w,h,c", [(540, 3, 1), (17, 9, 3), (2, 2, 1), (3, 5, 2), (64, 1, 1), (1, 64, 1), (300, 200, 3)])
+@pytest.mark.parametrize("gauss", [True, False])
+def test_blur(oracle, ref, w, h, c, gauss):
+    x = (np.random.default_rng(w * h).random((c, h, w)) * 255).astype(np.float32)
+    assert np.array_equal(bits(oracle.blur(x, 2.0, 0 if gauss else 1)), bits(ref.cimg_blur(x, 2.0, gauss)))
+
+
+@pytest.mark.parametrize("w,h", [(1081, 527), (67, 33), (4, 2), (3, 3), (135, 65), (600, 800)])
+def test_resize(oracle, ref, w, h):
+    rng = np.random.default_rng(w + h)
+    w2, h2 = max(1, w // 2), max(1, h // 2)
+    x = (rng.random((3, h, w)) * 255).astype(np.float32)
+    assert np.array_equal(bits(oracle.decimate(x, w2, h2)), bits(ref.cimg_resize(x, w2, h2)))
+    y = (rng.random((3, h2, w2)) * 255).astype(np.float32)
+    assert np.array_equal(bits(oracle.expand(y, w, h)), bits(ref.cimg_resize(y, w, h)))
+
+
+@pytest.mark.parametrize("w,h", [(67, 33), (270, 131), (333, 222), (100, 64), (33, 67), (640, 480)])
+def test_blend(oracle, ref, w, h):
+    for a_left in (True, False):
+        A, B = oracle.synth(w, h, 21), oracle.synth(w, h, 22)
+        if a_left:
+            A[:, :, (2 * w) // 3:] = 0
+            B[:, :, : w // 3] = 0
+        else:
+            A[:, :, : w // 3] = 0
+            B[:, :, (2 * w) // 3:] = 0
+        rc, out, _ = oracle.blend(A, B)
+        assert rc == 0 and np.array_equal(out, ref.blend(A, B))
+
+
+def test_equalize(oracle, ref):
+    for f in range(3):
+        img = oracle.synth(311, 173, 30 + f)
+        img[f % 3] = np.maximum(img[f % 3], 150 + 40 * f)
+        img[:, :50, :70] = 0
+        assert np.array_equal(oracle.equalize(img)[0], ref.equalize(img))
