@@ -46,6 +46,13 @@ class Seam(C.Structure):
         return (self.sum_a_x, self.n_a, self.sum_ov_x, self.n_ov, self.branch, self.start)
 
 
+class PairDesc(C.Structure):
+    """stitch_pair_desc: one independent stitch step of a batch (device pointers)."""
+    _fields_ = [("frame", C.c_void_p), ("fw", C.c_int), ("fh", C.c_int), ("p", C.c_double * 8), ("offx", C.c_float),
+                ("offy", C.c_float), ("mosaic", C.c_void_p), ("mw", C.c_int), ("mh", C.c_int), ("ox", C.c_int), ("oy", C.c_int),
+                ("out", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -289,11 +296,11 @@ def dev_quantize(src, out=None):
 class Plan:
     """stitch_plan: the device workspace of one canvas size (pyramids, scratch, tables, seam record)."""
 
-    def __init__(self, cw, ch, opts=None):
+    def __init__(self, cw, ch, opts=None, max_pairs=1):
         self._h = C.c_void_p()
-        self.cw, self.ch = int(cw), int(ch)
+        self.cw, self.ch, self.max_pairs = int(cw), int(ch), int(max_pairs)
         o = _opts(opts)
-        _chk(lib().stitch_plan_create(self.cw, self.ch, C.byref(o), C.byref(self._h)))
+        _chk(lib().stitch_plan_create_batched(self.cw, self.ch, C.byref(o), self.max_pairs, C.byref(self._h)))
         lw, lh = (C.c_int * 32)(), (C.c_int * 32)()
         n = _chk(lib().stitch_plan_levels(self._h, lw, lh))
         self.level_w, self.level_h = list(lw[:n]), list(lh[:n])
@@ -336,11 +343,34 @@ class Plan:
             mosaic.shape[2], mosaic.shape[1], int(ox), int(oy), _dp(out), _stream()))
         return out
 
-    def status(self):
-        """Wait for the last call and return its Seam; raises StitchError for an empty mid row / zero overlap."""
+    def pairs(self, items):
+        """Enqueue n <= max_pairs independent pairs as ONE launch sequence.  items: iterable of
+        (frame, p, offx, offy, mosaic, ox, oy, out) with device tensors; returns the list of `out` tensors."""
+        items = list(items)
+        arr = (PairDesc * len(items))()
+        sfx = None
+        for d, (frame, p, offx, offy, mosaic, ox, oy, out) in zip(arr, items):
+            frame, mosaic, out = _timg(frame), _timg(mosaic), _timg(out)
+            assert tuple(out.shape) == (3, self.ch, self.cw) and out.dtype == frame.dtype == mosaic.dtype
+            sfx = _tsfx(frame) if sfx is None else sfx
+            assert sfx == _tsfx(frame), "one pixel type per batch"
+            d.frame, d.fw, d.fh = frame.data_ptr(), frame.shape[2], frame.shape[1]
+            d.p = _map8(p)
+            d.offx, d.offy = float(offx), float(offy)
+            d.mosaic, d.mw, d.mh = mosaic.data_ptr(), mosaic.shape[2], mosaic.shape[1]
+            d.ox, d.oy, d.out = int(ox), int(oy), out.data_ptr()
+        _chk(getattr(lib(), "stitch_dev_pairs_" + sfx)(self._h, arr, len(items), _stream()))
+        return [it[7] for it in items]
+
+    def status(self, index=0):
+        """Wait for the last call and return pair `index`'s Seam; raises StitchError for an empty mid row / zero
+        overlap of that pair."""
         s = Seam()
-        _chk(lib().stitch_plan_status(self._h, C.byref(s)))
+        _chk(lib().stitch_plan_status_at(self._h, int(index), C.byref(s)))
         return s
+
+    def set_profiling_kernel(self, name):
+        _chk(lib().stitch_plan_set_profiling_kernel(self._h, KERNELS.index(name)))
 
     def set_profiling(self, on):
         _chk(lib().stitch_plan_set_profiling(self._h, int(bool(on))))

@@ -175,6 +175,8 @@ struct ProfRec {
 struct stitch_plan {
     int device = 0;
     int cw = 0, ch = 0, L = 0;
+    int cap = 1;     // pairs per launch sequence this workspace can hold (planes of pair b follow pair b-1)
+    int last_n = 0;  // pairs of the last call
     stitch_blend_opts opts{};
     Level lv[32]{};
     void* arena = nullptr;
@@ -191,6 +193,7 @@ struct stitch_plan {
     bool blur_skip = false;
     bool no_fuse = false;  // STITCH_NO_FUSE=1: keep blur and decimation as separate kernels (A/B and tests)
     bool profiling = false;
+    int prof_only = -1;  // >= 0: record events only around launches of this kernel id
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> free_events;
 };
@@ -202,7 +205,8 @@ struct StageTimer {  // records a pair of events around a group of launches when
     hipStream_t s;
     ProfRec r{};
     bool on;
-    StageTimer(stitch_plan* plan, hipStream_t st, int stage, int level) : p(plan), s(st), on(plan->profiling) {
+    StageTimer(stitch_plan* plan, hipStream_t st, int stage, int level)
+        : p(plan), s(st), on(plan->profiling && (plan->prof_only < 0 || plan->prof_only == stage)) {
         if (!on) return;
         r.stage = stage;
         r.level = level;
@@ -233,11 +237,12 @@ int launch_check(const char* what) {
 }
 
 // REDUCE for every level (ImageProcess.cpp:705-715): blur(G_l) into T, decimate T into G_{l+1}.
-int run_reduce(stitch_plan* p, hipStream_t s) {
+int run_reduce(stitch_plan* p, int n, hipStream_t s) {
+    const int np = 7 * n;  // planes in flight: every launch covers all pairs of the batch
     for (int l = 0; l + 1 < p->L; ++l) {
         const Level& a = p->lv[l];
         const Level& b = p->lv[l + 1];
-        const long lines = 7L * a.h;
+        const long lines = (long)np * a.h;
         const bool do_x = a.w > 1 && !p->blur_skip, do_y = a.h > 1 && !p->blur_skip;
         bool decimated = false;
         if (p->opts.blur_kind == 0) {
@@ -252,9 +257,9 @@ int run_reduce(stitch_plan* p, hipStream_t s) {
                     k_vv_x_bwd<<<nb, 64, 0, s>>>(p->T, a.w, a.pitch, lines, p->vvk, p->state);
                 }
             } else
-                HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * 7, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * np, hipMemcpyDeviceToDevice, s));
             if (do_y) {
-                dim3 g(a.pitch / 64, 7);
+                dim3 g(a.pitch / 64, np);
                 {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
                     k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
@@ -267,55 +272,58 @@ int run_reduce(stitch_plan* p, hipStream_t s) {
                     k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
             }
         } else {
-            HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * 7, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * np, hipMemcpyDeviceToDevice, s));
             if (do_x) {
                 StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
                 k_deriche<<<(int)((lines + 63) / 64), 64, 0, s>>>(p->T, p->T2, a.w, 1, a.pitch, a.h, a.ps, lines, p->drk);
             }
             if (do_y) {
                 StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
-                const long cols = 7L * a.w;
+                const long cols = (long)np * a.w;
                 k_deriche<<<(int)((cols + 63) / 64), 64, 0, s>>>(p->T, p->T2, a.h, a.pitch, 1, a.w, a.ps, cols, p->drk);
             }
         }
         if (!decimated) {
             StageTimer t(p, s, STITCH_K_DECIMATE, l);
-            k_decimate<<<grid_xy(b.pitch, b.h, 7), 256, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, b.g, b.w, b.h, b.pitch, b.ps);
+            k_decimate<<<grid_xy(b.pitch, b.h, np), 256, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, b.g, b.w, b.h, b.pitch, b.ps);
         }
     }
     return launch_check("reduce");
 }
 
 template <typename OUT>
-int run_collapse(stitch_plan* p, OUT* d_out, hipStream_t s) {
+int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s) {
     const int L = p->L;
     {
         const Level& t = p->lv[L - 1];
         StageTimer tm(p, s, STITCH_K_COLLAPSE, L - 1);
-        k_blend_top<<<grid_xy(t.pitch, t.h), 256, 0, s>>>(t.g, t.pitch, t.h, t.ps, t.e);
-        if (L == 1) k_emit_top<OUT><<<grid_xy(t.w, t.h), 256, 0, s>>>(t.e, t.w, t.h, t.pitch, t.ps, d_out);
+        k_blend_top<<<grid_xy(t.pitch, t.h, n), 256, 0, s>>>(t.g, t.pitch, t.h, t.ps, t.e);
+        if (L == 1) k_emit_top<OUT><<<grid_xy(t.w, t.h, n), 256, 0, s>>>(t.e, t.w, t.h, t.pitch, t.ps, outs);
     }
     for (int l = L - 2; l >= 0; --l) {
         const Level& a = p->lv[l];
-        const Level& n = p->lv[l + 1];
+        const Level& nx = p->lv[l + 1];
         StageTimer tm(p, s, STITCH_K_COLLAPSE, l);
         ExpandTab tb{a.ix, a.ax, a.iy, a.ay};
         if (l == 0)
-            k_collapse<OUT, true><<<grid_xy(a.w, a.h), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, n.g, n.e, n.w, n.h, n.pitch,
-                                                                    n.ps, tb, d_out, a.w, (size_t)a.w * a.h);
-        else
-            k_collapse<float, false><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, n.g, n.e, n.w, n.h,
-                                                                           n.pitch, n.ps, tb, a.e, a.pitch, a.ps);
+            k_collapse<OUT, true><<<grid_xy(a.w, (a.h + CROWS - 1) / CROWS, n), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h,
+                                                                       nx.pitch, nx.ps, tb, outs, a.w, (size_t)a.w * a.h);
+        else {
+            OutPtrs<float> eo{};
+            eo.p[0] = a.e;
+            k_collapse<float, false><<<grid_xy(a.pitch, (a.h + CROWS - 1) / CROWS, n), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w,
+                                                                              nx.h, nx.pitch, nx.ps, tb, eo, a.pitch, a.ps);
+        }
     }
     return launch_check("collapse");
 }
 
-int run_seam_mask(stitch_plan* p, hipStream_t s) {
+int run_seam_mask(stitch_plan* p, int n, hipStream_t s) {
     const Level& a = p->lv[0];
     StageTimer t(p, s, STITCH_K_SEAM_MASK, 0);
-    k_seam<<<1, 1024, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam);
-    k_mask<<<grid_xy(a.pitch, a.h), 256, 0, s>>>(a.g + 6 * a.ps, a.w, a.pitch, p->d_seam);
-    HIPCHK(hipMemcpyAsync(p->h_seam, p->d_seam, sizeof(SeamDev), hipMemcpyDeviceToHost, s));
+    k_seam<<<n, 1024, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam);
+    k_mask<<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(a.g, a.w, a.pitch, a.ps, p->d_seam);
+    HIPCHK(hipMemcpyAsync(p->h_seam, p->d_seam, sizeof(SeamDev) * n, hipMemcpyDeviceToHost, s));
     return launch_check("seam/mask");
 }
 
@@ -337,35 +345,78 @@ int dev_blend(stitch_plan* p, const PX* d_a, const PX* d_b, PX* d_out, void* str
         StageTimer t(p, s, STITCH_K_COMPOSE, 0);
         k_load_canvases<PX><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(d_a, d_b, a.g, a.w, a.h, a.pitch, a.ps);
     }
-    if ((rc = run_seam_mask(p, s))) return rc;
-    if ((rc = run_reduce(p, s))) return rc;
-    if ((rc = run_collapse<PX>(p, d_out, s))) return rc;
+    if ((rc = run_seam_mask(p, 1, s))) return rc;
+    if ((rc = run_reduce(p, 1, s))) return rc;
+    OutPtrs<PX> outs{};
+    outs.p[0] = d_out;
+    if ((rc = run_collapse<PX>(p, 1, outs, s))) return rc;
     p->last_stream = s;
     p->pending = true;
+    p->last_n = 1;
+    return STITCH_OK;
+}
+
+// n independent pairs (n <= plan capacity) through one launch sequence: every kernel covers all n pairs.
+template <typename PX>
+int dev_pairs(stitch_plan* p, const stitch_pair_desc* d, int n, void* stream) {
+    if (!p || !d) return fail(STITCH_ERR_ARG, "null plan or descriptor array");
+    if (n < 1 || n > p->cap) return fail(STITCH_ERR_ARG, "pairs: n=%d outside 1..%d (plan capacity)", n, p->cap);
+    int dev = -1;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev != p->device) return fail(STITCH_ERR_ARG, "plan belongs to device %d, current device is %d", p->device, dev);
+    PairArgs<PX> pa{};
+    OutPtrs<PX> outs{};
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].frame || !d[i].mosaic || !d[i].out || d[i].fw <= 0 || d[i].fh <= 0 || d[i].mw <= 0 || d[i].mh <= 0)
+            return fail(STITCH_ERR_ARG, "pairs: descriptor %d has a null buffer or a non-positive size", i);
+        pa.frame[i] = static_cast<const PX*>(d[i].frame);
+        pa.mosaic[i] = static_cast<const PX*>(d[i].mosaic);
+        pa.out[i] = static_cast<PX*>(d[i].out);
+        outs.p[i] = pa.out[i];
+        std::memcpy(pa.map[i].p, d[i].p, sizeof pa.map[i].p);
+        pa.fw[i] = d[i].fw;
+        pa.fh[i] = d[i].fh;
+        pa.mw[i] = d[i].mw;
+        pa.mh[i] = d[i].mh;
+        pa.ox[i] = d[i].ox;
+        pa.oy[i] = d[i].oy;
+        pa.offx[i] = d[i].offx;
+        pa.offy[i] = d[i].offy;
+    }
+    hipStream_t s = as_stream(stream);
+    const Level& a = p->lv[0];
+    int rc;
+    {
+        StageTimer t(p, s, STITCH_K_COMPOSE, 0);
+        k_compose<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps);
+    }
+    if ((rc = run_seam_mask(p, n, s))) return rc;
+    if ((rc = run_reduce(p, n, s))) return rc;
+    if ((rc = run_collapse<PX>(p, n, outs, s))) return rc;
+    p->last_stream = s;
+    p->pending = true;
+    p->last_n = n;
     return STITCH_OK;
 }
 
 template <typename PX>
 int dev_pair(stitch_plan* p, const PX* d_frame, int fw, int fh, const double pm[8], float offx, float offy,
              const PX* d_mosaic, int mw, int mh, int ox, int oy, PX* d_out, void* stream) {
-    int rc = check_plan_call(p, d_frame, d_mosaic, d_out);
-    if (rc) return rc;
-    if (!pm || fw <= 0 || fh <= 0 || mw <= 0 || mh <= 0) return fail(STITCH_ERR_ARG, "pair: bad frame/mosaic size or null map");
-    hipStream_t s = as_stream(stream);
-    const Level& a = p->lv[0];
-    MapP m;
-    std::memcpy(m.p, pm, sizeof m.p);
-    {
-        StageTimer t(p, s, STITCH_K_COMPOSE, 0);
-        k_compose<PX><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(d_frame, fw, fh, m, offx, offy, d_mosaic, mw, mh, ox, oy, a.g, a.w,
-                                                           a.h, a.pitch, a.ps);
-    }
-    if ((rc = run_seam_mask(p, s))) return rc;
-    if ((rc = run_reduce(p, s))) return rc;
-    if ((rc = run_collapse<PX>(p, d_out, s))) return rc;
-    p->last_stream = s;
-    p->pending = true;
-    return STITCH_OK;
+    if (!pm) return fail(STITCH_ERR_ARG, "pair: null map");
+    stitch_pair_desc d{};
+    d.frame = d_frame;
+    d.fw = fw;
+    d.fh = fh;
+    std::memcpy(d.p, pm, sizeof d.p);
+    d.offx = offx;
+    d.offy = offy;
+    d.mosaic = d_mosaic;
+    d.mw = mw;
+    d.mh = mh;
+    d.ox = ox;
+    d.oy = oy;
+    d.out = d_out;
+    return dev_pairs<PX>(p, &d, 1, stream);
 }
 
 void seam_to_public(const SeamDev& d, stitch_seam* o) {
@@ -675,7 +726,12 @@ int stitch_dev_move_f32(const float* d_src, int sw, int sh, int ox, int oy, floa
 }
 
 int stitch_plan_create(int cw, int ch, const stitch_blend_opts* opts, stitch_plan** plan_out) {
+    return stitch_plan_create_batched(cw, ch, opts, 1, plan_out);
+}
+
+int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, int max_pairs, stitch_plan** plan_out) {
     if (!plan_out) return fail(STITCH_ERR_ARG, "plan_create: null plan_out");
+    if (max_pairs < 1 || max_pairs > MAXB) return fail(STITCH_ERR_ARG, "plan_create: max_pairs must be 1..%d", MAXB);
     *plan_out = nullptr;
     int rc = need_device();
     if (rc) return rc;
@@ -693,6 +749,8 @@ int stitch_plan_create(int cw, int ch, const stitch_blend_opts* opts, stitch_pla
     p->cw = cw;
     p->ch = ch;
     p->L = L;
+    p->cap = max_pairs;
+    const size_t B = (size_t)max_pairs;
     p->opts = o;
     p->vvk = make_vvk(o.sigma);
     p->drk = make_drk(o.sigma);
@@ -716,8 +774,8 @@ int stitch_plan_create(int cw, int ch, const stitch_blend_opts* opts, stitch_pla
         v.h = lh[l];
         v.pitch = round_up(v.w, 64);
         v.ps = (size_t)v.pitch * v.h;
-        g_off[l] = take(sizeof(float) * (v.ps * 7 + (size_t)v.pitch * 64));
-        e_off[l] = l >= 1 || L == 1 ? take(sizeof(float) * v.ps * 3) : 0;
+        g_off[l] = take(sizeof(float) * (v.ps * 7 * B + (size_t)v.pitch * 64));
+        e_off[l] = l >= 1 || L == 1 ? take(sizeof(float) * v.ps * 3 * B) : 0;
         if (l + 1 < L) {
             ix_off[l] = take(sizeof(int32_t) * v.w);
             ax_off[l] = take(sizeof(double) * v.w);
@@ -726,12 +784,12 @@ int stitch_plan_create(int cw, int ch, const stitch_blend_opts* opts, stitch_pla
         }
     }
     const Level& v0 = p->lv[0];
-    const size_t t_bytes = sizeof(float) * (v0.ps * 7 + (size_t)v0.pitch * 64);
+    const size_t t_bytes = sizeof(float) * (v0.ps * 7 * B + (size_t)v0.pitch * 64);
     const size_t t_off = take(t_bytes);
     const size_t t2_off = o.blur_kind == 1 ? take(t_bytes) : 0;
-    const size_t state_n = 4 * 7 * (size_t)std::max(v0.h + 64, v0.pitch);
+    const size_t state_n = 4 * 7 * B * (size_t)std::max(v0.h + 64, v0.pitch);
     const size_t st_off = take(sizeof(double) * state_n);
-    const size_t seam_off = take(sizeof(SeamDev));
+    const size_t seam_off = take(sizeof(SeamDev) * B);
     p->arena_bytes = off;
     if (hipMalloc(&p->arena, off) != hipSuccess) {
         (void)hipGetLastError();
@@ -755,7 +813,7 @@ int stitch_plan_create(int cw, int ch, const stitch_blend_opts* opts, stitch_pla
     p->state = reinterpret_cast<double*>(base + st_off);
     p->d_seam = reinterpret_cast<SeamDev*>(base + seam_off);
     // the slack rows and pitch padding are read by partial tiles: give them defined (zero) contents once
-    if (hipMemset(p->arena, 0, off) != hipSuccess || hipHostMalloc((void**)&p->h_seam, sizeof(SeamDev)) != hipSuccess) {
+    if (hipMemset(p->arena, 0, off) != hipSuccess || hipHostMalloc((void**)&p->h_seam, sizeof(SeamDev) * B) != hipSuccess) {
         stitch_plan_destroy(p);
         return fail(STITCH_ERR_HIP, "plan_create: workspace initialisation failed");
     }
@@ -774,7 +832,7 @@ int stitch_plan_create(int cw, int ch, const stitch_blend_opts* opts, stitch_pla
             return fail(STITCH_ERR_HIP, "plan_create: table upload failed");
         }
     }
-    std::memset(p->h_seam, 0, sizeof(SeamDev));
+    std::memset(p->h_seam, 0, sizeof(SeamDev) * B);
     *plan_out = p;
     return STITCH_OK;
 }
@@ -819,21 +877,43 @@ int stitch_dev_pair_f32(stitch_plan* plan, const float* d_frame, int fw, int fh,
     return dev_pair(plan, d_frame, fw, fh, p, offx, offy, d_mosaic, mw, mh, ox, oy, d_out, stream);
 }
 
-int stitch_plan_status(stitch_plan* p, stitch_seam* seam_out) {
+int stitch_plan_status_at(stitch_plan* p, int index, stitch_seam* seam_out) {
     if (!p) return fail(STITCH_ERR_ARG, "null plan");
+    if (index < 0 || index >= p->cap) return fail(STITCH_ERR_ARG, "status: index %d outside the plan's capacity %d", index, p->cap);
     if (p->pending) {
         HIPCHK(hipStreamSynchronize(p->last_stream));
         p->pending = false;
     }
-    seam_to_public(*p->h_seam, seam_out);
-    if (p->h_seam->status == -2) return fail(STITCH_ERR_EMPTY_MIDROW, "blend: channel 0 of a's middle row is empty");
-    if (p->h_seam->status == -3) return fail(STITCH_ERR_ZERO_OVERLAP, "blend: a and b do not overlap on the middle row");
+    const SeamDev& sd = p->h_seam[index];
+    seam_to_public(sd, seam_out);
+    if (sd.status == -2) return fail(STITCH_ERR_EMPTY_MIDROW, "blend: channel 0 of a's middle row is empty (pair %d)", index);
+    if (sd.status == -3) return fail(STITCH_ERR_ZERO_OVERLAP, "blend: a and b do not overlap on the middle row (pair %d)", index);
     return STITCH_OK;
+}
+
+int stitch_plan_status(stitch_plan* p, stitch_seam* seam_out) { return stitch_plan_status_at(p, 0, seam_out); }
+
+int stitch_plan_capacity(const stitch_plan* p) { return p ? p->cap : 0; }
+
+int stitch_dev_pairs_u8(stitch_plan* plan, const stitch_pair_desc* pairs, int n, void* stream) {
+    return dev_pairs<uint8_t>(plan, pairs, n, stream);
+}
+int stitch_dev_pairs_f32(stitch_plan* plan, const stitch_pair_desc* pairs, int n, void* stream) {
+    return dev_pairs<float>(plan, pairs, n, stream);
 }
 
 int stitch_plan_set_profiling(stitch_plan* p, int enabled) {
     if (!p) return fail(STITCH_ERR_ARG, "null plan");
     p->profiling = enabled != 0;
+    p->prof_only = -1;
+    return STITCH_OK;
+}
+
+int stitch_plan_set_profiling_kernel(stitch_plan* p, int kernel_id) {
+    if (!p) return fail(STITCH_ERR_ARG, "null plan");
+    if (kernel_id < 0 || kernel_id >= STITCH_K_COUNT) return fail(STITCH_ERR_ARG, "bad kernel id %d", kernel_id);
+    p->profiling = true;
+    p->prof_only = kernel_id;
     return STITCH_OK;
 }
 

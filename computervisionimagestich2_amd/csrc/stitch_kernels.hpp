@@ -147,23 +147,38 @@ __global__ __launch_bounds__(256) void k_move(const PX* __restrict__ src, int sw
 }
 
 // ---- S1: compose = warp + move + value cast, straight into the level-0 planes -------------------------------
-// ImageProcess.cpp:218-224 + :680-681.  Level-0 planes: [a0 a1 a2 b0 b1 b2 mask], pitched, plane stride ps.
-// The zero canvases of the reference are implicit: an out-of-range pixel is written as 0.
+// ImageProcess.cpp:218-224 + :680-681.  Level-0 planes of pair b: [a0 a1 a2 b0 b1 b2 mask], pitched, plane
+// stride ps, pairs stacked (7*ps apart).  The zero canvases of the reference are implicit: an out-of-range pixel
+// is written as 0.  A launch covers every pair of the batch (blockIdx.z = pair).
+constexpr int MAXB = 8;  // pairs per plan / launch
 template <typename PX>
-__global__ __launch_bounds__(256) void k_compose(const PX* __restrict__ frame, int fw, int fh, MapP m, float offx,
-                                                 float offy, const PX* __restrict__ mosaic, int mw, int mh, int ox,
-                                                 int oy, float* __restrict__ g0, int cw, int ch, int pitch, size_t ps) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+struct PairArgs {
+    const PX* frame[MAXB];
+    const PX* mosaic[MAXB];
+    PX* out[MAXB];
+    MapP map[MAXB];
+    int fw[MAXB], fh[MAXB], mw[MAXB], mh[MAXB], ox[MAXB], oy[MAXB];
+    float offx[MAXB], offy[MAXB];
+};
+
+template <typename PX>
+__global__ __launch_bounds__(256) void k_compose(PairArgs<PX> pa, float* __restrict__ g0_all, int cw, int ch, int pitch,
+                                                 size_t ps) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, pr = blockIdx.z;
     if (x >= pitch) return;
+    float* g0 = g0_all + (size_t)pr * 7 * ps;
     float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
     if (x < cw) {
+        const PX* __restrict__ frame = pa.frame[pr];
+        const PX* __restrict__ mosaic = pa.mosaic[pr];
+        const int fw = pa.fw[pr], fh = pa.fh[pr], mw = pa.mw[pr], mh = pa.mh[pr];
         int nx, ny;
-        if (map_to_src(m, (float)x + offx, (float)y + offy, fw, fh, nx, ny)) {
+        if (map_to_src(pa.map[pr], (float)x + pa.offx[pr], (float)y + pa.offy[pr], fw, fh, nx, ny)) {
             const size_t spl = (size_t)fw * fh, so = (size_t)ny * fw + nx;
 #pragma unroll
             for (int c = 0; c < 3; ++c) a[c] = (float)px_store<PX>(warp_tap((float)frame[so + c * spl]));
         }
-        const long long mx = (long long)x + ox, my = (long long)y + oy;
+        const long long mx = (long long)x + pa.ox[pr], my = (long long)y + pa.oy[pr];
         if (mx >= 0 && mx < mw && my >= 0 && my < mh) {
             const size_t spl = (size_t)mw * mh, so = (size_t)my * mw + mx;
 #pragma unroll
@@ -201,10 +216,12 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(1024) void k_seam(const float* __restrict__ g0, int cw, int ch, int pitch, size_t ps,
-                                               int seam_rule, SeamDev* __restrict__ out) {
+__global__ __launch_bounds__(1024) void k_seam(const float* __restrict__ g0_all, int cw, int ch, int pitch, size_t ps,
+                                               int seam_rule, SeamDev* __restrict__ out_all) {
     __shared__ int red[4][16];
     const int mid = ch / 2;
+    const float* g0 = g0_all + (size_t)blockIdx.x * 7 * ps;  // one workgroup per pair
+    SeamDev* out = out_all + blockIdx.x;
     const float* a0 = g0 + (size_t)mid * pitch;
     const float* b0 = a0 + 3 * ps;
     int s_a = 0, n_a = 0, s_o = 0, n_o = 0;
@@ -280,9 +297,12 @@ __global__ __launch_bounds__(1024) void k_seam(const float* __restrict__ g0, int
 }
 
 // mask level 0: a vertical step (ImageProcess.cpp:682,690-698), plane 6 of level 0
-__global__ __launch_bounds__(256) void k_mask(float* __restrict__ m0, int cw, int pitch, const SeamDev* __restrict__ seam) {
+__global__ __launch_bounds__(256) void k_mask(float* __restrict__ g0_all, int cw, int pitch, size_t ps,
+                                              const SeamDev* __restrict__ seam_all) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= pitch) return;
+    float* m0 = g0_all + ((size_t)blockIdx.z * 7 + 6) * ps;
+    const SeamDev* seam = seam_all + blockIdx.z;
     float v = 0.f;
     if (x < cw) v = seam->branch == 0 ? ((double)x < seam->thr ? 1.f : 0.f) : (x >= seam->start ? 1.f : 0.f);
     m0[(size_t)y * pitch + x] = v;
@@ -813,10 +833,12 @@ __device__ __forceinline__ float blend_ref(float a, float b, float m) {
 }
 
 // top level: E = a*m + b*(1-m) on the Gaussian top (no Laplacian, no clamp); E has 3 pitched planes.
-__global__ __launch_bounds__(256) void k_blend_top(const float* __restrict__ g, int pitch, int h, size_t ps,
-                                                   float* __restrict__ e) {
+__global__ __launch_bounds__(256) void k_blend_top(const float* __restrict__ g_all, int pitch, int h, size_t ps,
+                                                   float* __restrict__ e_all) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= pitch) return;
+    const float* g = g_all + (size_t)blockIdx.z * 7 * ps;
+    float* e = e_all + (size_t)blockIdx.z * 3 * ps;
     const size_t o = (size_t)y * pitch + x;
     const float m = g[o + 6 * ps];
 #pragma unroll
@@ -826,40 +848,93 @@ __global__ __launch_bounds__(256) void k_blend_top(const float* __restrict__ g, 
 // level l < L-1:  La = Ga_l - EXPAND(Ga_{l+1}), Lb likewise (float subtract, CImg.h:12096-12107);
 // S = blend(La, Lb, m_l);  E_l = clamp(S + EXPAND(E_{l+1}), 0, 255) (ImageProcess.cpp:766-769).
 // OUT = float planes (pitched, next collapse input) or the final dense canvas (float, or uint8_t by truncation).
+template <typename OUT>
+struct OutPtrs {
+    OUT* p[MAXB];
+};
+// One work-item owns one column of a strip of CROWS output rows.  EXPAND's x pass depends only on the source row,
+// and consecutive output rows share their source rows (iy advances by at most one per output row when
+// up-sampling), so the x-interpolated values of the two current source rows are kept in registers and only a newly
+// entered source row is interpolated: the double-precision work per pixel halves, the values are the same floats.
+constexpr int CROWS = 8;
 template <typename OUT, bool DENSE>
-__global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g, int w, int h, int pitch, size_t ps,
-                                                  const float* __restrict__ gn, const float* __restrict__ en, int sw,
-                                                  int sh, int spitch, size_t sps, ExpandTab tb, OUT* __restrict__ out,
+__global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_all, int w, int h, int pitch, size_t ps,
+                                                  const float* __restrict__ gn_all, const float* __restrict__ en_all, int sw,
+                                                  int sh, int spitch, size_t sps, ExpandTab tb, OutPtrs<OUT> outs,
                                                   int opitch, size_t ops) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * CROWS, pr = blockIdx.z;
     if (x >= (DENSE ? w : pitch)) return;
+    const float* g = g_all + (size_t)pr * 7 * ps;
+    const float* gn = gn_all + (size_t)pr * 7 * sps;
+    const float* en = en_all + (size_t)pr * 3 * sps;
+    OUT* __restrict__ out = DENSE ? outs.p[pr] : outs.p[0] + (size_t)pr * 3 * ops;
+    const int y1 = min(y0 + CROWS, h);
     if (!DENSE && x >= w) {
+        for (int y = y0; y < y1; ++y)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) out[(size_t)y * opitch + x + c * ops] = OUT(0);
+            for (int c = 0; c < 3; ++c) out[(size_t)y * opitch + x + c * ops] = OUT(0);
         return;
     }
-    const ExpandPos e = expand_pos(tb, x, y, sw, sh, spitch);
-    const size_t o = (size_t)y * pitch + x;
-    const float m = g[o + 6 * ps];
+    const int ix = tb.ix[x], ix2 = ix < sw - 1 ? ix + 1 : ix;
+    const double ax = tb.ax[x];
+    const bool x_nearest = (sw == 1), y_nearest = (sh == 1);
+    // x pass of one source row for the nine planes that are expanded: a0..a2, b0..b2 of G_{l+1}, then E_{l+1}
+    auto xrow = [&](int row, float X[9]) {
+        const size_t o1 = (size_t)row * spitch + ix, o2 = (size_t)row * spitch + ix2;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float la = g[o + c * ps] - expand_at(gn + c * sps, e);
-        const float lb = g[o + (3 + c) * ps] - expand_at(gn + (3 + c) * sps, e);
-        const float s = blend_ref(la, lb, m);
-        float v = s + expand_at(en + c * sps, e);
-        if (v > 255.f)
-            v = 255.f;
-        else if (v < 0.f)
-            v = 0.f;
-        out[(size_t)y * opitch + x + c * ops] = px_store<OUT>(v);
+        for (int q = 0; q < 9; ++q) {
+            const float* pl = q < 6 ? gn + q * sps : en + (q - 6) * sps;
+            X[q] = x_nearest ? pl[o1] : lerp_ref(ax, pl[o1], pl[o2]);
+        }
+    };
+    float X1[9], X2[9];
+    int cur1 = -1, cur2 = -1;
+    for (int y = y0; y < y1; ++y) {
+        const int iy = tb.iy[y], iy2 = iy < sh - 1 ? iy + 1 : iy;
+        const double ay = tb.ay[y];
+        if (iy != cur1) {
+            if (iy == cur2) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) X1[q] = X2[q];
+            } else
+                xrow(iy, X1);
+            cur1 = iy;
+        }
+        if (iy2 != cur2) {
+            if (iy2 == cur1) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) X2[q] = X1[q];
+            } else
+                xrow(iy2, X2);
+            cur2 = iy2;
+        }
+        const size_t o = (size_t)y * pitch + x;
+        const float m = g[o + 6 * ps];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float ea = y_nearest ? X1[c] : lerp_ref(ay, X1[c], X2[c]);
+            const float eb = y_nearest ? X1[3 + c] : lerp_ref(ay, X1[3 + c], X2[3 + c]);
+            const float ee = y_nearest ? X1[6 + c] : lerp_ref(ay, X1[6 + c], X2[6 + c]);
+            const float la = g[o + c * ps] - ea;
+            const float lb = g[o + (3 + c) * ps] - eb;
+            const float s_ = blend_ref(la, lb, m);
+            float v = s_ + ee;
+            if (v > 255.f)
+                v = 255.f;
+            else if (v < 0.f)
+                v = 0.f;
+            out[(size_t)y * opitch + x + c * ops] = px_store<OUT>(v);
+        }
     }
 }
 
 // single-level pyramid (max side 2 or 3): the result is the top-level blend itself, cast to the output type
 template <typename OUT>
-__global__ void k_emit_top(const float* __restrict__ e, int w, int h, int pitch, size_t ps, OUT* __restrict__ out) {
+__global__ void k_emit_top(const float* __restrict__ e_all, int w, int h, int pitch, size_t ps, OutPtrs<OUT> outs) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    const float* e = e_all + (size_t)blockIdx.z * 3 * ps;
+    OUT* __restrict__ out = outs.p[blockIdx.z];
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[(size_t)c * w * h + (size_t)y * w + x] = px_store<OUT>(e[(size_t)y * pitch + x + c * ps]);
 }

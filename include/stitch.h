@@ -125,6 +125,11 @@ int stitch_dev_move_f32(const float *d_src, int sw, int sh, int ox, int oy, floa
  * the blur scratch, the collapse chain, the resize tables, the seam record).  Create it once per canvas size
  * on the device that will run it; calls on one plan must be serialised by the caller (one stream at a time). */
 int stitch_plan_create(int cw, int ch, const stitch_blend_opts *opts, stitch_plan **plan_out);
+/* Workspace for up to max_pairs (1..8) independent pairs of the same canvas size processed by ONE launch sequence
+ * (every kernel covers all pairs: the batch configs of BASELINE.json -- more independent lines per launch for the
+ * recursive filters, fewer launches per pair). */
+int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts *opts, int max_pairs, stitch_plan **plan_out);
+int stitch_plan_capacity(const stitch_plan *plan);
 void stitch_plan_destroy(stitch_plan *plan);
 size_t stitch_plan_workspace_bytes(const stitch_plan *plan);
 int stitch_plan_levels(const stitch_plan *plan, int *level_w, int *level_h);
@@ -136,9 +141,24 @@ int stitch_dev_pair_u8(stitch_plan *plan, const uint8_t *d_frame, int fw, int fh
                        void *stream);
 int stitch_dev_pair_f32(stitch_plan *plan, const float *d_frame, int fw, int fh, const double p[8], float offx,
                         float offy, const float *d_mosaic, int mw, int mh, int ox, int oy, float *d_out, void *stream);
+/* One independent stitch step (ImageProcess.cpp:218-230) of a batch; buffers are device pointers of the call's
+ * pixel type (uint8_t for _u8, float for _f32); `out` is the dense cw x ch x 3 mosaic. */
+typedef struct stitch_pair_desc {
+    const void *frame;  /* image to warp (the reference's imgs[dst].projectedSrc)                              */
+    int fw, fh;
+    double p[8];        /* backward map {H00,H01,H02,H10,H11,H12,H20,H21}                                       */
+    float offx, offy;   /* min_x, min_y as passed to warpingImageByHomography                                   */
+    const void *mosaic; /* running mosaic to move (the reference's `result`)                                    */
+    int mw, mh;
+    int ox, oy;         /* integer offsets as passed to movingImageByOffset                                     */
+    void *out;
+} stitch_pair_desc;
+int stitch_dev_pairs_u8(stitch_plan *plan, const stitch_pair_desc *pairs, int n, void *stream);
+int stitch_dev_pairs_f32(stitch_plan *plan, const stitch_pair_desc *pairs, int n, void *stream);
 /* Waits for the plan's last call to finish and reports its seam outcome: STITCH_OK, STITCH_ERR_EMPTY_MIDROW or
  * STITCH_ERR_ZERO_OVERLAP (in the error cases the output buffer holds unspecified finite values). */
-int stitch_plan_status(stitch_plan *plan, stitch_seam *seam_out);
+int stitch_plan_status(stitch_plan *plan, stitch_seam *seam_out);                   /* pair 0 */
+int stitch_plan_status_at(stitch_plan *plan, int index, stitch_seam *seam_out);    /* pair `index` of a batch */
 
 /* Per-kernel device timing of a plan's calls, with HIP events recorded on the call's stream around every
  * launch.  Kernel ids: */
@@ -154,6 +174,8 @@ enum {
     STITCH_K_COUNT = 8
 };
 int stitch_plan_set_profiling(stitch_plan *plan, int enabled);
+/* Record events only around launches of one kernel id (near-zero overhead inside a timed region). */
+int stitch_plan_set_profiling_kernel(stitch_plan *plan, int kernel_id);
 /* Sums since profiling was enabled or last read; synchronises the plan's stream.  total_ms[k] / launches[k] is
  * the average launch duration of kernel k over all pyramid levels; level0_ms[k] is the finest level's share. */
 int stitch_plan_read_profile(stitch_plan *plan, double total_ms[STITCH_K_COUNT], int launches[STITCH_K_COUNT],

@@ -180,3 +180,40 @@ def test_config2_full_size_against_oracle(st, gpu, oracle, dtype):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"within tolerance ({err}) but not bit-equal"
         # size-independent properties of the float mosaic: clamped range, pure-a / pure-b regions far from the seam
         assert got.min() >= 0.0 and got.max() <= 255.0
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("n", [1, 3, 4])
+def test_batched_plan_matches_single_pairs(st, gpu, oracle, dtype, n):
+    """stitch_dev_pairs_*: n independent pairs through ONE launch sequence = n single-pair results (config 4's
+    per-GPU shard).  Pairs differ in frames, maps, offsets; one of them has an odd frame size."""
+    import torch
+    from computervisionimagestich2_amd import capi
+    cw, ch = 768, 384
+    plan = capi.Plan(cw, ch, max_pairs=4)
+    items, refs = [], []
+    for i in range(n):
+        fw, fh = (512, 384) if i != 1 else (501, 377)
+        A, B = oracle.synth(fw, fh, 2 * i, dtype), oracle.synth(fw, fh, 2 * i + 1, dtype)
+        P = [1.0, 0.002, 1e-6, -256.0 - 8.0 * i, -0.001, 1.0, 5e-7, 1.5]
+        offx, offy, ox, oy = (0.0, 0.0, 0, 0) if i != 2 else (-3.25, 1.5, -3, 1)
+        rc, ref = oracle.pair(B, P, offx, offy, A, ox, oy, cw, ch)
+        assert rc == 0
+        refs.append(ref)
+        out = torch.empty((3, ch, cw), dtype=torch.uint8 if dtype == np.uint8 else torch.float32, device=gpu)
+        items.append((torch.from_numpy(B).to(gpu), P, offx, offy, torch.from_numpy(A).to(gpu), ox, oy, out))
+    outs = plan.pairs(items)
+    for i in range(n):
+        plan.status(i)
+        got = outs[i].cpu().numpy()
+        assert np.array_equal(got.view(np.uint8), refs[i].view(np.uint8)), i
+    # a failing pair is reported for its own index only
+    if n >= 2 and dtype == np.uint8:
+        bad = list(items[1])
+        bad[4] = torch.zeros_like(items[1][4])  # empty mosaic -> zero overlap for pair 1
+        plan.pairs([items[0], tuple(bad)])
+        plan.status(0)
+        with pytest.raises(st.StitchError) as e:
+            plan.status(1)
+        assert e.value.code == st.capi.ERR_ZERO_OVERLAP
+    plan.close()
