@@ -184,6 +184,8 @@ struct stitch_plan {
     float* T = nullptr;   // blur scratch, 7 planes of level 0 + slack
     float* T2 = nullptr;  // Deriche temporaries (blur_kind 1 only)
     double* state = nullptr;
+    float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
+    bool mask_opt = false;  // level-0 mask handled implicitly (Van Vliet, level-0 height a multiple of 64)
     SeamDev* d_seam = nullptr;
     SeamDev* h_seam = nullptr;  // pinned
     hipStream_t last_stream = nullptr;
@@ -245,16 +247,23 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s) {
         const long lines = (long)np * a.h;
         const bool do_x = a.w > 1 && !p->blur_skip, do_y = a.h > 1 && !p->blur_skip;
         bool decimated = false;
+        MaskL0 mk{};
+        if (l == 0 && p->mask_opt) {
+            mk.seam = p->d_seam;
+            mk.side = p->side;
+            mk.h = a.h;
+            mk.enabled = 1;
+        }
         if (p->opts.blur_kind == 0) {
             if (do_x) {
                 const int nb = (int)((lines + TS - 1) / TS);
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
-                    k_vv_x_fwd<<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state);
+                    k_vv_x_fwd<<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk);
                 }
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
-                    k_vv_x_bwd<<<nb, 64, 0, s>>>(p->T, a.w, a.pitch, lines, p->vvk, p->state);
+                    k_vv_x_bwd<<<nb, 64, 0, s>>>(p->T, a.w, a.pitch, lines, p->vvk, p->state, mk);
                 }
             } else
                 HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * np, hipMemcpyDeviceToDevice, s));
@@ -262,7 +271,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s) {
                 dim3 g(a.pitch / 64, np);
                 {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
-                    k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
+                    k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk);
                 }
                 StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
                 if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
@@ -305,14 +314,14 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s)
         const Level& nx = p->lv[l + 1];
         StageTimer tm(p, s, STITCH_K_COLLAPSE, l);
         ExpandTab tb{a.ix, a.ax, a.iy, a.ay};
-        if (l == 0)
-            k_collapse<OUT, true><<<grid_xy(a.w, (a.h + CROWS - 1) / CROWS, n), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h,
-                                                                       nx.pitch, nx.ps, tb, outs, a.w, (size_t)a.w * a.h);
+        if (l == 0)  // level 0: the mask is the seam's step function itself (never read from memory)
+            k_collapse<OUT, true><<<grid_xy(a.w, (a.h + CROWS - 1) / CROWS, n), 256, 0, s>>>(
+                a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, tb, outs, a.w, (size_t)a.w * a.h, p->d_seam);
         else {
             OutPtrs<float> eo{};
             eo.p[0] = a.e;
             k_collapse<float, false><<<grid_xy(a.pitch, (a.h + CROWS - 1) / CROWS, n), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w,
-                                                                              nx.h, nx.pitch, nx.ps, tb, eo, a.pitch, a.ps);
+                                                                              nx.h, nx.pitch, nx.ps, tb, eo, a.pitch, a.ps, nullptr);
         }
     }
     return launch_check("collapse");
@@ -322,7 +331,7 @@ int run_seam_mask(stitch_plan* p, int n, hipStream_t s) {
     const Level& a = p->lv[0];
     StageTimer t(p, s, STITCH_K_SEAM_MASK, 0);
     k_seam<<<n, 1024, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam);
-    k_mask<<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(a.g, a.w, a.pitch, a.ps, p->d_seam);
+    if (!p->mask_opt) k_mask<<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(a.g, a.w, a.pitch, a.ps, p->d_seam);
     HIPCHK(hipMemcpyAsync(p->h_seam, p->d_seam, sizeof(SeamDev) * n, hipMemcpyDeviceToHost, s));
     return launch_check("seam/mask");
 }
@@ -790,6 +799,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     const size_t state_n = 4 * 7 * B * (size_t)std::max(v0.h + 64, v0.pitch);
     const size_t st_off = take(sizeof(double) * state_n);
     const size_t seam_off = take(sizeof(SeamDev) * B);
+    const size_t side_off = take(sizeof(float) * B * v0.pitch);
     p->arena_bytes = off;
     if (hipMalloc(&p->arena, off) != hipSuccess) {
         (void)hipGetLastError();
@@ -812,6 +822,9 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     p->T2 = o.blur_kind == 1 ? reinterpret_cast<float*>(base + t2_off) : nullptr;
     p->state = reinterpret_cast<double*>(base + st_off);
     p->d_seam = reinterpret_cast<SeamDev*>(base + seam_off);
+    p->side = reinterpret_cast<float*>(base + side_off);
+    // implicit level-0 mask: needs both Van Vliet sweeps at level 0 and 64-row blocks that do not straddle planes
+    p->mask_opt = !p->no_fuse && o.blur_kind == 0 && !p->blur_skip && L >= 2 && v0.w > 1 && v0.h > 1 && (v0.h % 64) == 0;
     // the slack rows and pitch padding are read by partial tiles: give them defined (zero) contents once
     if (hipMemset(p->arena, 0, off) != hipSuccess || hipHostMalloc((void**)&p->h_seam, sizeof(SeamDev) * B) != hipSuccess) {
         stitch_plan_destroy(p);

@@ -340,10 +340,25 @@ __device__ __forceinline__ void tile_store(float* __restrict__ base, int pitch, 
         *reinterpret_cast<f4*>(p + (size_t)(4 * i) * pitch) = *reinterpret_cast<const f4*>(t + (4 * i) * TP);
 }
 
+// Level-0 mask without a level-0 mask plane.  The reference's mask[0] is a vertical step (ImageProcess.cpp:690-698):
+// every row is the same function of x, so (when the level height is a multiple of 64, i.e. a 64-row block never
+// straddles planes) the x sweeps generate the step on the fly, compute only the first 64 of its identical rows,
+// leave the x-blurred row in a small side buffer, and the causal y sweep reads that one row for every y.  The
+// collapse kernel evaluates the step directly.  Saves one plane write and six plane reads/writes of level 0.
+struct MaskL0 {
+    const SeamDev* seam;  // per pair
+    float* side;          // [pairs][pitch]: the x-blurred mask row
+    int h;                // level height = lines per plane
+    int enabled;
+};
+__device__ __forceinline__ float mask_step(const SeamDev& sd, int x) {
+    return sd.branch == 0 ? ((double)x < sd.thr ? 1.f : 0.f) : (x >= sd.start ? 1.f : 0.f);
+}
+
 // `lines` = rows of all planes stacked (plane stride = pitch*h, so line L starts at L*pitch); the buffers are
 // allocated with 64 spare rows so that a partial last block may touch rows >= lines without leaving them.
 __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, float* __restrict__ out, int w, int pitch,
-                                                  long lines, VVK k, double* __restrict__ state) {
+                                                  long lines, VVK k, double* __restrict__ state, MaskL0 mk) {
     __shared__ __attribute__((aligned(16))) float tile[TS * TP];
     const int lane = threadIdx.x;
     const long line0 = (long)blockIdx.x * TS, line = line0 + lane;
@@ -351,13 +366,42 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
     float* ob = out + (size_t)line0 * pitch;
     const int ntiles = (w + TS - 1) / TS;
     const bool live = line < lines;
-    double iplus = live ? (double)in[(size_t)line * pitch + (w - 1)] : 0.0;  // CImg.h:34906
+    bool gen_mask = false;  // wave-uniform: this block's 64 lines are rows of a level-0 mask plane
+    SeamDev sd;
+    if (mk.enabled) {
+        const long plane = line0 / mk.h;
+        if (plane % 7 == 6) {
+            if (line0 % mk.h >= TS) return;  // rows 64.. of the step are copies of rows 0..63 and are never read
+            gen_mask = true;
+            sd = mk.seam[plane / 7];
+        }
+    }
+    auto gen_tile = [&](int c0, f4 pre[16]) {
+        f4 v;
+        const int c = c0 + ((lane & 15) << 2);
+        v.x = mask_step(sd, c);
+        v.y = mask_step(sd, c + 1);
+        v.z = mask_step(sd, c + 2);
+        v.w = mask_step(sd, c + 3);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pre[i] = v;
+    };
+    double iplus = 0.0;  // CImg.h:34906
+    if (live) iplus = gen_mask ? (double)mask_step(sd, w - 1) : (double)in[(size_t)line * pitch + (w - 1)];
     double v1 = 0, v2 = 0, v3 = 0;
     f4 pre[16];
-    tile_load(ib, pitch, 0, lane, pre);
+    if (gen_mask)
+        gen_tile(0, pre);
+    else
+        tile_load(ib, pitch, 0, lane, pre);
     for (int t = 0; t < ntiles; ++t) {
         tile_to_lds(tile, lane, pre);
-        if (t + 1 < ntiles) tile_load(ib, pitch, (t + 1) * TS, lane, pre);
+        if (t + 1 < ntiles) {
+            if (gen_mask)
+                gen_tile((t + 1) * TS, pre);
+            else
+                tile_load(ib, pitch, (t + 1) * TS, lane, pre);
+        }
         __syncthreads();  // one wave per workgroup: orders the tile writes before the per-lane row reads
         float* row = tile + lane * TP;
         const int jmax = min(TS, w - t * TS);
@@ -415,10 +459,18 @@ __device__ __forceinline__ void triggs(const VVK& k, double iplus, double& v1, d
 }
 
 __global__ __launch_bounds__(64) void k_vv_x_bwd(float* __restrict__ data, int w, int pitch, long lines, VVK k,
-                                                  const double* __restrict__ state) {
+                                                  const double* __restrict__ state, MaskL0 mk) {
     __shared__ __attribute__((aligned(16))) float tile[TS * TP];
     const int lane = threadIdx.x;
     const long line0 = (long)blockIdx.x * TS, line = line0 + lane;
+    float* side_row = nullptr;  // level-0 mask plane: row 0 of this block is also left in the side buffer
+    if (mk.enabled) {
+        const long plane = line0 / mk.h;
+        if (plane % 7 == 6) {
+            if (line0 % mk.h >= TS) return;
+            side_row = mk.side + (size_t)(plane / 7) * pitch;
+        }
+    }
     float* base = data + (size_t)line0 * pitch;
     const int ntiles = (w + TS - 1) / TS;
     const bool live = line < lines;
@@ -479,6 +531,7 @@ __global__ __launch_bounds__(64) void k_vv_x_bwd(float* __restrict__ data, int w
         }
         __syncthreads();
         tile_store(base, pitch, t * TS, lane, tile);
+        if (side_row && lane < 16) *reinterpret_cast<f4*>(side_row + t * TS + (lane << 2)) = *reinterpret_cast<const f4*>(tile + (lane << 2));
     }
 }
 
@@ -553,13 +606,17 @@ __device__ __forceinline__ void stream_rows(const float* __restrict__ p, int pit
 }
 
 __global__ __launch_bounds__(64) void k_vv_y_fwd(float* __restrict__ data, int h, int pitch, size_t ps, VVK k,
-                                                  double* __restrict__ state) {
+                                                  double* __restrict__ state, MaskL0 mk) {
     const int x = blockIdx.x * WAVE + threadIdx.x;
     float* p = data + blockIdx.y * ps + x;
-    const double iplus = (double)p[(size_t)(h - 1) * pitch];
+    // level-0 mask plane: every input row is the one x-blurred row kept in the side buffer (row stride 0)
+    const bool side = mk.enabled && (blockIdx.y % 7 == 6);
+    const float* src = side ? mk.side + (size_t)(blockIdx.y / 7) * pitch + x : p;
+    const int spitch = side ? 0 : pitch;
+    const double iplus = (double)src[(size_t)(h - 1) * spitch];
     double v1, v2, v3;
-    v1 = v2 = v3 = (double)p[0] / k.sumsq;
-    stream_rows<true>(p, pitch, 0, h, [&](int y, float xv) {
+    v1 = v2 = v3 = (double)src[0] / k.sumsq;
+    stream_rows<true>(src, spitch, 0, h, [&](int y, float xv) {
         double v0 = (double)xv;
         v0 += v1 * k.f1;
         v0 += v2 * k.f2;
@@ -861,7 +918,7 @@ template <typename OUT, bool DENSE>
 __global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_all, int w, int h, int pitch, size_t ps,
                                                   const float* __restrict__ gn_all, const float* __restrict__ en_all, int sw,
                                                   int sh, int spitch, size_t sps, ExpandTab tb, OutPtrs<OUT> outs,
-                                                  int opitch, size_t ops) {
+                                                  int opitch, size_t ops, const SeamDev* __restrict__ seam_l0) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * CROWS, pr = blockIdx.z;
     if (x >= (DENSE ? w : pitch)) return;
     const float* g = g_all + (size_t)pr * 7 * ps;
@@ -889,6 +946,7 @@ __global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_al
     };
     float X1[9], X2[9];
     int cur1 = -1, cur2 = -1;
+    const float m_step = seam_l0 ? mask_step(seam_l0[pr], x) : 0.f;  // level 0: the mask is the step itself
     for (int y = y0; y < y1; ++y) {
         const int iy = tb.iy[y], iy2 = iy < sh - 1 ? iy + 1 : iy;
         const double ay = tb.ay[y];
@@ -909,7 +967,7 @@ __global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_al
             cur2 = iy2;
         }
         const size_t o = (size_t)y * pitch + x;
-        const float m = g[o + 6 * ps];
+        const float m = seam_l0 ? m_step : g[o + 6 * ps];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float ea = y_nearest ? X1[c] : lerp_ref(ay, X1[c], X2[c]);
