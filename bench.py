@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frame", type=int, default=4096, help="frame edge of the CPU baseline's bounded sample")
     ap.add_argument("--no-kernel-events", action="store_true", help="time without per-launch HIP events")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-pair-in-flight latency measurement")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -172,7 +173,7 @@ def main():
 
     # single pair in flight (config 2 as a latency figure), untimed by events
     single_ms = None
-    if world == 1:
+    if world == 1 and not args.no_single:
         for k in range(2):
             step(k, 1)
         torch.cuda.synchronize()
@@ -212,16 +213,17 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                    te = json.load(open(tpath)).get(dom, {})
+                    traffic = te.get("hbm_bytes_per_launch") if te.get("batch") == B and F == 4096 else None
                 except Exception:
                     traffic = None
             pilot_tot = sum(v[0] for v in pilot.values())
-            line["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            line["roofline"] = {"bound": "hbm", "kernel": capi.KERNEL_SYMBOLS[dom].replace("<T,", "<float,"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                                 "avg_launch_ms": round(ms / launches, 5), "launches": launches,
                                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                                 "share_of_device_time": round(pilot[dom][0] / pilot_tot, 4),
-                                "note": "average over all pyramid levels of this kernel; events on the launch stream inside the timed region"}
+                                "note": "average over every launch of this kernel symbol in the timed region (all pyramid levels it runs on); HIP events on the launch stream"}
         line["kernels"] = {k_: {"ms_per_pair": round(v[0] / PILOT / B, 4), "launches_per_step": v[1] // PILOT,
                                 "level0_ms_per_pair": round(v[2] / PILOT / B, 4),
                                 "algorithmic_GBps": round(per_kernel[k_] / (v[0] / PILOT / B / 1e3) / 1e9, 1) if v[0] > 0 else None}

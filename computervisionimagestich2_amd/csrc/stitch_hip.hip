@@ -305,14 +305,14 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s)
     const int L = p->L;
     {
         const Level& t = p->lv[L - 1];
-        StageTimer tm(p, s, STITCH_K_COLLAPSE, L - 1);
+        StageTimer tm(p, s, STITCH_K_COLLAPSE_TOP, L - 1);
         k_blend_top<<<grid_xy(t.pitch, t.h, n), 256, 0, s>>>(t.g, t.pitch, t.h, t.ps, t.e);
         if (L == 1) k_emit_top<OUT><<<grid_xy(t.w, t.h, n), 256, 0, s>>>(t.e, t.w, t.h, t.pitch, t.ps, outs);
     }
     for (int l = L - 2; l >= 0; --l) {
         const Level& a = p->lv[l];
         const Level& nx = p->lv[l + 1];
-        StageTimer tm(p, s, STITCH_K_COLLAPSE, l);
+        StageTimer tm(p, s, l == 0 ? STITCH_K_COLLAPSE_L0 : STITCH_K_COLLAPSE, l);
         ExpandTab tb{a.ix, a.ax, a.iy, a.ay};
         if (l == 0)  // level 0: the mask is the seam's step function itself (never read from memory)
             k_collapse<OUT, true><<<grid_xy(a.w, (a.h + CROWS - 1) / CROWS, n), 256, 0, s>>>(
@@ -329,9 +329,14 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s)
 
 int run_seam_mask(stitch_plan* p, int n, hipStream_t s) {
     const Level& a = p->lv[0];
-    StageTimer t(p, s, STITCH_K_SEAM_MASK, 0);
-    k_seam<<<n, 1024, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam);
-    if (!p->mask_opt) k_mask<<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(a.g, a.w, a.pitch, a.ps, p->d_seam);
+    {
+        StageTimer t(p, s, STITCH_K_SEAM, 0);
+        k_seam<<<n, 1024, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam);
+    }
+    if (!p->mask_opt) {
+        StageTimer t(p, s, STITCH_K_MASK, 0);
+        k_mask<<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(a.g, a.w, a.pitch, a.ps, p->d_seam);
+    }
     HIPCHK(hipMemcpyAsync(p->h_seam, p->d_seam, sizeof(SeamDev) * n, hipMemcpyDeviceToHost, s));
     return launch_check("seam/mask");
 }

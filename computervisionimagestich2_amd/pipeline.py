@@ -43,10 +43,13 @@ def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample
     line = sum(2 * 7 * 4 * n[l] for l in range(L - 1))  # one recursive pass: read 7 planes, write 7 planes
     per_kernel = {
         "compose": s1,
-        "seam_mask": 4 * P,  # mask step written once (the two mid rows read are negligible)
+        "seam": 2 * 4 * level_w[0],  # two mid rows
+        "mask": 4 * P,               # the step written once (when it is materialised at all)
         "vv_x_fwd": line, "vv_x_bwd": line, "vv_y_fwd": line, "vv_y_bwd": line,
         "decimate": sum(7 * 4 * (n[l] + n[l + 1]) for l in range(L - 1)),
-        "collapse": s3,
+        "collapse_top": 4 * 10 * n[L - 1],
+        "collapse": sum(4 * (10 * n[l] + 9 * n[l + 1]) for l in range(1, L - 1)),
+        "collapse_l0": 4 * (10 * n[0] + 9 * n[1]) if L > 1 else 0,
     }
     return per_kernel, {"S1": s1, "S2": s2, "S3": s3, "total": s1 + s2 + s3}
 

@@ -163,15 +163,18 @@ int stitch_plan_status_at(stitch_plan *plan, int index, stitch_seam *seam_out); 
 /* Per-kernel device timing of a plan's calls, with HIP events recorded on the call's stream around every
  * launch.  Kernel ids: */
 enum {
-    STITCH_K_COMPOSE = 0,   /* k_compose / k_load_canvases: warp + move + value cast -> level-0 planes            */
-    STITCH_K_SEAM_MASK = 1, /* k_seam + k_mask: mid-row scan, mask step                                           */
-    STITCH_K_VV_X_FWD = 2,  /* recursive Gaussian along rows, causal pass (Deriche: whole x pass)                 */
-    STITCH_K_VV_X_BWD = 3,  /* recursive Gaussian along rows, anticausal pass                                     */
-    STITCH_K_VV_Y_FWD = 4,  /* recursive Gaussian along columns, causal pass (Deriche: whole y pass)              */
-    STITCH_K_VV_Y_BWD = 5,  /* recursive Gaussian along columns, anticausal pass                                  */
-    STITCH_K_DECIMATE = 6,  /* moving-average halving                                                             */
-    STITCH_K_COLLAPSE = 7,  /* expand + Laplacian + per-level blend + collapse (and the top-level blend)          */
-    STITCH_K_COUNT = 8
+    STITCH_K_COMPOSE = 0,      /* k_compose (pairs) / k_load_canvases (blend): warp + move + value cast -> level 0 */
+    STITCH_K_SEAM = 1,         /* k_seam: mid-row scan                                                           */
+    STITCH_K_MASK = 2,         /* k_mask: level-0 mask plane (only when it is not handled implicitly)            */
+    STITCH_K_VV_X_FWD = 3,     /* k_vv_x_fwd: recursive Gaussian along rows, causal (Deriche: whole x pass)      */
+    STITCH_K_VV_X_BWD = 4,     /* k_vv_x_bwd: anticausal                                                         */
+    STITCH_K_VV_Y_FWD = 5,     /* k_vv_y_fwd: along columns, causal (Deriche: whole y pass)                      */
+    STITCH_K_VV_Y_BWD = 6,     /* k_vv_y_bwd_dec (fused with the decimation) / k_vv_y_bwd: anticausal            */
+    STITCH_K_DECIMATE = 7,     /* k_decimate: stand-alone moving-average halving                                 */
+    STITCH_K_COLLAPSE_TOP = 8, /* k_blend_top: blend of the coarsest level                                       */
+    STITCH_K_COLLAPSE = 9,     /* k_collapse<float,false>: expand + Laplacian + blend + collapse, levels 1..L-2  */
+    STITCH_K_COLLAPSE_L0 = 10, /* k_collapse<T,true>: the same at level 0, writing the dense output canvas       */
+    STITCH_K_COUNT = 11
 };
 int stitch_plan_set_profiling(stitch_plan *plan, int enabled);
 /* Record events only around launches of one kernel id (near-zero overhead inside a timed region). */

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 --pmc passes of scripts/pmc.sh (gpurun_out/pmc/) into profiles/traffic.json.
+
+HBM bytes per kernel = 2*FETCH_SIZE + WRITE_SIZE, both counters in KiB.  The factor 2 on FETCH_SIZE is the gfx950
+correction of /opt/skills/guides/MI355X_MICROARCH.md ("FETCH_SIZE reports exactly half of the bytes of a wide
+coalesced streaming read"); it is checked here against a kernel whose bytes are known exactly (k_vv_x_fwd at level
+0 reads n_pairs*6 planes of the canvas and writes 7 -- the calibration line printed below).  Counters come from
+separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+steps_total = int(sys.argv[3]) if len(sys.argv) > 3 else 6  # warmup 1 + pilot 3 + timed 2 of scripts/pmc.sh
+
+GROUP = {"k_compose": "compose", "k_seam": "seam", "k_mask": "mask", "k_vv_x_fwd": "vv_x_fwd",
+         "k_vv_x_bwd": "vv_x_bwd", "k_vv_y_fwd": "vv_y_fwd", "k_vv_y_bwd_dec": "vv_y_bwd", "k_vv_y_bwd": "vv_y_bwd",
+         "k_decimate": "decimate", "k_collapse<float, false>": "collapse", "k_collapse<float, true>": "collapse_l0",
+         "k_collapse<unsigned char, true>": "collapse_l0", "k_blend_top": "collapse_top"}
+LAUNCH_GROUPS = {"compose": 1, "seam": 1, "mask": 1, "vv_x_fwd": 11, "vv_x_bwd": 11, "vv_y_fwd": 11, "vv_y_bwd": 11, "decimate": 0,
+                 "collapse_top": 1, "collapse": 10, "collapse_l0": 1}
+
+
+def kname(full):
+    s = full.replace("void ", "")
+    s = s[s.index("sk::") + 4:] if "sk::" in s else s
+    if "(" in s:
+        s = s[: s.index("(")]
+    if s.startswith("k_collapse<"):
+        return s
+    return s[: s.index("<")] if "<" in s else s
+
+
+def counter(name):
+    f = glob.glob(os.path.join(src, name, "runc", "*counter_collection.csv"))[0]
+    tot = collections.defaultdict(float)
+    mx = collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != name:
+            continue
+        k = kname(r["Kernel_Name"])
+        tot[k] += float(r["Counter_Value"])
+        mx[k] = max(mx[k], float(r["Counter_Value"]))
+    return tot, mx
+
+
+fetch, fmax = counter("FETCH_SIZE")
+write, wmax = counter("WRITE_SIZE")
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    g = GROUP.get(k)
+    if g is None:
+        continue
+    e = out.setdefault(g, {"fetch_kib_per_step": 0.0, "write_kib_per_step": 0.0, "kernels": []})
+    e["fetch_kib_per_step"] += fetch.get(k, 0) / steps_total
+    e["write_kib_per_step"] += write.get(k, 0) / steps_total
+    e["kernels"].append(k)
+for g, e in out.items():
+    hbm = (2 * e["fetch_kib_per_step"] + e["write_kib_per_step"]) * 1024
+    e["hbm_bytes_per_step"] = int(hbm)
+    e["hbm_bytes_per_pair"] = int(hbm / batch)
+    n = LAUNCH_GROUPS.get(g, 0)
+    e["launch_groups_per_step"] = n
+    e["hbm_bytes_per_launch"] = int(hbm / n) if n else None
+    e["batch"] = batch
+out["_meta"] = {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, averaged over the run's steps",
+                "calibration_k_vv_x_fwd_level0": {"FETCH_SIZE_KiB_max": fmax.get("k_vv_x_fwd"), "WRITE_SIZE_KiB_max": wmax.get("k_vv_x_fwd")},
+                "source": os.path.relpath(src, ROOT), "batch": batch, "steps": steps_total}
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+tot = sum(e["hbm_bytes_per_pair"] for g, e in out.items() if not g.startswith("_"))
+for g, e in out.items():
+    if not g.startswith("_"):
+        print(f"{g:10s} {e['hbm_bytes_per_pair'] / 1e9:7.3f} GB/pair")
+print(f"total      {tot / 1e9:7.3f} GB/pair")

@@ -26,7 +26,7 @@ def test_algorithmic_bytes_match_survey():
     lw = [4096 >> i for i in range(12)]
     _, st2 = pipeline.algorithmic_bytes(4096 * 4096, 4096 * 4096, lw, lw, 4)
     assert round(st2["total"] / 1e9, 3) == 3.937  # the 4096x4096 canvas figure of the same section
-    assert per_kernel["collapse"] == st["S3"] and per_kernel["compose"] == st["S1"]
+    assert per_kernel["collapse"] + per_kernel["collapse_l0"] + per_kernel["collapse_top"] == st["S3"] and per_kernel["compose"] == st["S1"]
 
 
 def test_config_recipes():
