@@ -74,6 +74,20 @@ def cpu_baseline(sample_frame, verbose=False):
             "single_thread_value": round(res[1], 4), "host_cores": ncores}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout when a communicator is created; keep stdout for the ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     args = parse()
     import torch
@@ -89,9 +103,21 @@ def main():
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # STITCH_FORCE_DIST=1 runs the N>1 code path (RCCL init, quantise, asynchronous all-gather) with a single rank --
+    # a rehearsal of the multi-GPU path on a one-GPU box; it is never set by the driver
+    force_dist = world == 1 and os.environ.get("STITCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        with _StdoutToStderr():
+            if force_dist:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29517")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()  # creates the communicator now (and its banner), not inside the timed region
+            torch.cuda.synchronize()
 
     F = args.frame
     cw, ch = pipeline.config_canvas(F)
@@ -113,7 +139,7 @@ def main():
     outs = [[torch.empty((3, ch, cw), dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(2)]
     # N>1: finished mosaics travel as unsigned char (the reference's output type) through pipeline.MosaicGather --
     # the class the gloo tests cover -- asynchronously, so the gather of step k overlaps the kernels of step k+1
-    gather = pipeline.MosaicGather((B, 3, ch, cw), dev, world, rank, slots=2) if world > 1 else None
+    gather = pipeline.MosaicGather((B, 3, ch, cw), dev, world, rank, slots=2, force_collective=force_dist) if use_dist else None
 
     def step(k, n=B):
         items = [it + (outs[k % 2][q],) for q, it in enumerate(batches[k % n_distinct][:n])]
@@ -152,18 +178,18 @@ def main():
         plan.set_profiling_kernel(dom)
     plan.read_profile()
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(K):
         step(W + PILOT + k)
     drain()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -235,8 +261,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_frame, args.verbose)
         print(json.dumps(line), flush=True)
+    if gather is not None and rank == 0 and os.environ.get("STITCH_CHECK_GATHER") == "1":
+        # rehearsal check: the last gathered block holds this rank's own quantised mosaics
+        last = (W + PILOT + K - 1)
+        own = gather.out[last % 2][rank]
+        ok = all(torch.equal(own[q], capi.dev_quantize(outs[last % 2][q])) for q in range(B))
+        print(f"[gather check] own mosaics in the gathered block: {'ok' if ok else 'MISMATCH'}", file=sys.stderr)
     plan.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -107,10 +107,11 @@ class MosaicGather:
 
     Pairs are independent, so this end-of-pair exchange is the only communication of the batch configs."""
 
-    def __init__(self, shape, device, world, rank, slots=2, keep=False, steps=0, group=None):
+    def __init__(self, shape, device, world, rank, slots=2, keep=False, steps=0, group=None, force_collective=False):
         import torch
         self.torch = torch
         self.world, self.rank, self.slots, self.keep, self.group = world, rank, slots, keep, group
+        self.force_collective = force_collective  # issue the collective even with one rank (rehearsal of the N>1 path)
         self.inp = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(slots)]
         n_out = steps if keep else slots
         self.out = [torch.empty((world,) + tuple(shape), dtype=torch.uint8, device=device) for _ in range(n_out)]
@@ -128,7 +129,7 @@ class MosaicGather:
         import torch.distributed as dist
         s = k % self.slots
         out = self.out[k if self.keep else s]
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             out[0].copy_(self.inp[s])
             return
         # output viewed as the concatenation along dim 0 (the layout every backend accepts)
