@@ -217,3 +217,29 @@ def test_batched_plan_matches_single_pairs(st, gpu, oracle, dtype, n):
             plan.status(1)
         assert e.value.code == st.capi.ERR_ZERO_OVERLAP
     plan.close()
+
+
+def test_config5_size_single_gpu_against_oracle(st, gpu, oracle):
+    """BASELINE.json configs[4]'s problem size (one 16384x16384x3 f32 pair -> 24576x16384 canvas, 14 levels) on ONE
+    GPU ("replicas only" for the multi-GPU form): the 30 GB plan fits HBM; compared in full with the
+    oracle (about half a minute on the box's cores)."""
+    import torch
+    from computervisionimagestich2_amd import capi, pipeline
+    F = 16384
+    cw, ch = pipeline.config_canvas(F)
+    A, B = capi.dev_synth(F, F, 0, torch.float32, gpu), capi.dev_synth(F, F, 1, torch.float32, gpu)
+    p = pipeline.config_map(0, F)  # p[3] = -8192
+    plan = capi.Plan(cw, ch)
+    assert plan.levels == 14 and plan.level_w[-1] == 3 and plan.level_h[-1] == 2
+    out = plan.pair(B, p, 0.0, 0.0, A, 0, 0)
+    seam = plan.status()
+    got = out.cpu().numpy()
+    plan.close()
+    Ah, Bh = A.cpu().numpy(), B.cpu().numpy()
+    del A, B, out
+    torch.cuda.empty_cache()
+    rc, ref = oracle.pair(Bh, p, 0.0, 0.0, Ah, 0, 0, cw, ch)
+    assert rc == 0 and seam.branch == 1
+    err = float(np.abs(got - ref).max())
+    assert err <= TOL_F32, err
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"within tolerance ({err}) but not bit-equal"

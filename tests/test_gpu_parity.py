@@ -164,3 +164,33 @@ def test_equalize_lummix_finish(st, gpu, oracle, w, h):
     assert np.array_equal(hist2, rhist)
     assert np.array_equal(fin, mixed)
     assert np.array_equal(st.lummix(img, got, 5.0, 6.0), oracle.lummix(img, ref, 5.0, 6.0))
+
+
+def test_blend_random_sizes_sweep(st, gpu, oracle):
+    """Random canvas sizes (odd/even at every level -> fused and stand-alone decimation, implicit and materialised
+    level-0 mask, both seam branches) for both pixel types, against the oracle."""
+    rng = np.random.default_rng(4321)
+    done = 0
+    while done < 30:
+        w, h = int(rng.integers(2, 700)), int(rng.integers(2, 500))
+        if rng.random() < 0.3:
+            h = max(64, (h // 64) * 64)  # implicit-mask path needs a multiple of 64
+        dtype = np.uint8 if done % 2 == 0 else np.float32
+        A, B = oracle.synth(w, h, int(rng.integers(0, 50)), dtype), oracle.synth(w, h, int(rng.integers(50, 100)), dtype)
+        ca, cb = sorted(int(v) for v in rng.integers(0, w + 1, 2))
+        if rng.random() < 0.5:
+            A[:, :, cb:] = 0
+            B[:, :, :ca] = 0
+        else:
+            A[:, :, :ca] = 0
+            B[:, :, cb:] = 0
+        rc, ref, rs = oracle.blend(A, B)
+        if rc != 0:
+            with pytest.raises(st.StitchError) as e:
+                st.blend(A, B)
+            assert e.value.code == rc  # same status codes as the oracle (-2 empty mid row, -3 no overlap, -4 pyramid)
+            continue
+        got, s = st.blend(A, B)
+        assert s.as_tuple() == rs.as_tuple(), (w, h)
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (w, h, dtype)
+        done += 1

@@ -181,3 +181,15 @@ def test_synth_never_zero(oracle):
     for dt in (np.uint8, np.float32):
         f = oracle.synth(300, 100, 5, dt)
         assert f.min() >= 1 and f.max() <= 251
+
+
+def test_oracle_is_clean_under_asan_ubsan():
+    """the CPU restatement runs clean under -fsanitize=address,undefined (leak check on) and gives the
+    same checksum as the plain build (oracle/selftest.c)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(HERE)
+    r = subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "sanitize-check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sanitize-check ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

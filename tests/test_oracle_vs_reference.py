@@ -90,3 +90,39 @@ def test_equalize(oracle, ref):
         img[f % 3] = np.maximum(img[f % 3], 150 + 40 * f)
         img[:, :50, :70] = 0
         assert np.array_equal(oracle.equalize(img)[0], ref.equalize(img))
+
+
+def test_blend_random_sizes_sweep(oracle, ref):
+    """40 random canvas sizes (odd/even mixes at every pyramid level, both seam branches, ragged content): the oracle
+    equals the reference byte for byte or reports the degenerate-pyramid case the reference cannot express."""
+    rng = np.random.default_rng(1234)
+    done = 0
+    while done < 40:
+        w, h = int(rng.integers(2, 260)), int(rng.integers(2, 200))
+        n, _, _ = oracle.pyramid_levels(w, h)
+        A, B = oracle.synth(w, h, int(rng.integers(0, 50))), oracle.synth(w, h, int(rng.integers(50, 100)))
+        ca, cb = sorted(int(v) for v in rng.integers(0, w + 1, 2))
+        if rng.random() < 0.5:
+            A[:, :, cb:] = 0
+            B[:, :, :ca] = 0
+        else:
+            A[:, :, :ca] = 0
+            B[:, :, cb:] = 0
+        rc, out, seam = oracle.blend(A, B)
+        if n < 0:
+            assert rc == -4
+            continue
+        if rc != 0:
+            assert rc in (-2, -3)  # empty mid row / no overlap: the reference hangs or divides 0/0 here
+            continue
+        assert np.array_equal(out, ref.blend(A, B)), (w, h)
+        done += 1
+
+
+def test_bbox(oracle, ref):
+    # the reference's canvas sizing inputs (ImageProcess.cpp:206-216) -- used by stitch_canvas_bbox's test as well
+    p = [0.9724, -0.0398, 0.000149, 206.67, 0.00141, 1.00076, -1.2e-06, 4.55]
+    mn_x, mn_y, mx_x, mx_y = ref.bbox(384, 512, p)
+    corners = [oracle.map_xy(np.float32(x), np.float32(y), p) for x in (0, 383) for y in (0, 511)]
+    assert mn_x == min(c[0] for c in corners) and mx_x == max(c[0] for c in corners)
+    assert mn_y == min(c[1] for c in corners) and mx_y == max(c[1] for c in corners)
