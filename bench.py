@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- warp+blend MPix/s at 4096x4096x3 f32 (BASELINE.json), one process per GPU.
 
-A step = one pass of the hot path (warp + move + multi-band blend) over one batch of synthetic input: --batch
-(default 4) independent config-2 pairs per rank (two 4096x4096x3 f32 frames -> 6144x4096x3 f32 mosaic each; pair i
-of the config-4 family has p[3] = -2048 - 8i), processed by ONE launch sequence of the batched plan.  Frames are generated on the device before the timed
+A step = one pass of the hot path (warp + move + multi-band blend) over synthetic input: --streams (default 2)
+batches of --batch (default 4) independent config-2 pairs per rank (two 4096x4096x3 f32 frames -> 6144x4096x3 f32
+mosaic each; pair i of the config-4 family has p[3] = -2048 - 8i); a batch is ONE launch sequence of a batched plan
+on its own HIP stream.  Frames are generated on the device before the timed
 region, so every input is resident in HBM when timing starts.  Pairs are independent: no data-path collective;
 for N>1 each finished mosaic is cast to unsigned char (the reference's own output type) and all-gathered
 (RCCL over xGMI) on the communicator's stream while the next pair computes, so that every rank ends up holding
 the whole batch -- that exchange is inside the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (largest share of device time), timed
-with HIP events on the launch stream inside the timed region; `pipeline` gives the same accounting for the whole
-pair.  `cpu_baseline` (N=1, rank 0) times the oracle's CPU restatement on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  `value` comes from timed region 1 (all batches in flight).  `roofline` describes
+the dominant kernel (largest share of device time) in timed region 2, where one batch is in flight so that a
+launch's duration is the kernel's own, timed with HIP events on the launch stream; `pipeline` gives the byte
+accounting for the whole pair at the `value` rate.  `cpu_baseline` (N=1, rank 0) times the oracle's CPU restatement on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -30,7 +32,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="independent pairs per GPU per step (one launch sequence)")
+    ap.add_argument("--batch", type=int, default=4, help="independent pairs per batch (one launch sequence)")
+    ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU, each on its own HIP stream")
     ap.add_argument("--frame", type=int, default=4096, help="frame edge (4096 = the metric's configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frame", type=int, default=4096, help="frame edge of the CPU baseline's bounded sample")
@@ -121,97 +124,121 @@ def main():
 
     F = args.frame
     cw, ch = pipeline.config_canvas(F)
-    K, W, B = args.steps, args.warmup, args.batch
-    plan = capi.Plan(cw, ch, max_pairs=B)
+    K, W, B, S = args.steps, args.warmup, args.batch, args.streams
 
-    # inputs: this rank's pairs are [rank*K*B, (rank+1)*K*B) of the config-4 family (frames 2i, 2i+1; map
-    # p[3] = -F/2 - 8i), a few distinct batches cycled; everything is resident in HBM before timing starts
-    n_distinct = min(K + W, 4)
-    first = rank * K * B
-    batches = []
-    for j in range(n_distinct):
-        items = []
-        for q in range(B):
-            i = (first + j * B + q) % 32
-            items.append((capi.dev_synth(F, F, 2 * i + 1, torch.float32, dev), pipeline.config_map(i, F), 0.0, 0.0,
-                          capi.dev_synth(F, F, 2 * i, torch.float32, dev), 0, 0))
-        batches.append(items)
-    outs = [[torch.empty((3, ch, cw), dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(2)]
-    # N>1: finished mosaics travel as unsigned char (the reference's output type) through pipeline.MosaicGather --
-    # the class the gloo tests cover -- asynchronously, so the gather of step k overlaps the kernels of step k+1
-    gather = pipeline.MosaicGather((B, 3, ch, cw), dev, world, rank, slots=2, force_collective=force_dist) if use_dist else None
+    # S "lanes": each lane = one batched plan (B pairs per launch sequence) on its own HIP stream, so that the
+    # latency-bound small pyramid levels of one batch overlap the bandwidth-bound sweeps of the other.
+    # Inputs: this rank's pairs come from the config-4 family (frames 2i, 2i+1; map p[3] = -F/2 - 8i); a few distinct
+    # batches per lane are cycled; everything is resident in HBM before timing starts.
+    n_distinct = 2
+    first = rank * K * B * S
+    lanes = []
+    for ln in range(S):
+        batches = []
+        for j in range(n_distinct):
+            items = []
+            for q in range(B):
+                i = (first + (ln * n_distinct + j) * B + q) % 32
+                items.append((capi.dev_synth(F, F, 2 * i + 1, torch.float32, dev), pipeline.config_map(i, F), 0.0, 0.0,
+                              capi.dev_synth(F, F, 2 * i, torch.float32, dev), 0, 0))
+            batches.append(items)
+        lanes.append({
+            "plan": capi.Plan(cw, ch, max_pairs=B),
+            "stream": torch.cuda.Stream(device=dev),
+            "batches": batches,
+            "outs": [[torch.empty((3, ch, cw), dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(2)],
+            # N>1: finished mosaics travel as unsigned char (the reference's output type) through pipeline.MosaicGather
+            # -- the class the gloo tests cover -- asynchronously: the gather of step k overlaps the kernels of step k+1
+            "gather": pipeline.MosaicGather((B, 3, ch, cw), dev, world, rank, slots=2, force_collective=force_dist) if use_dist else None,
+        })
+    plan = lanes[0]["plan"]
 
-    def step(k, n=B):
-        items = [it + (outs[k % 2][q],) for q, it in enumerate(batches[k % n_distinct][:n])]
-        plan.pairs(items)
-        if gather is not None:
-            slot = gather.input_slot(k)
-            for q in range(n):
-                capi.dev_quantize(outs[k % 2][q], slot[q])
-            gather.submit(k)
+    def lane_step(ln, k, n=B):
+        L = lanes[ln]
+        with torch.cuda.stream(L["stream"]):
+            outs = L["outs"][k % 2]
+            L["plan"].pairs([it + (outs[q],) for q, it in enumerate(L["batches"][k % n_distinct][:n])])
+            if L["gather"] is not None:
+                slot = L["gather"].input_slot(k)
+                for q in range(n):
+                    capi.dev_quantize(outs[q], slot[q])
+                L["gather"].submit(k)
 
     def drain():
-        if gather is not None:
-            gather.drain()
+        for L in lanes:
+            if L["gather"] is not None:
+                with torch.cuda.stream(L["stream"]):
+                    L["gather"].drain()
         torch.cuda.synchronize()
 
-    for k in range(W):
-        step(k)
-    drain()
-    for q in range(B):
-        plan.status(q)  # raises if a seam scan failed
+    def timed(n_lanes, steps, k0):
+        """steps x (one batch on each of n_lanes lanes), bracketed by barrier + synchronize; max over ranks."""
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            for ln in range(n_lanes):
+                lane_step(ln, k0 + k)
+        drain()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
-    # pilot: every launch bracketed by HIP events (costs ~10 % wall, so it is NOT the timed region): per-kernel table
-    # and the choice of the dominant kernel
+    for k in range(W):
+        for ln in range(S):
+            lane_step(ln, k)
+    drain()
+    for L in lanes:
+        for q in range(B):
+            L["plan"].status(q)  # raises if a seam scan failed
+
+    # pilot (one lane, every launch bracketed by HIP events; ~10 % overhead, so never the timed region): per-kernel
+    # table and the choice of the dominant kernel
     plan.set_profiling(True)
     plan.read_profile()
     PILOT = 3
     for k in range(PILOT):
-        step(W + k)
+        lane_step(0, W + k)
     drain()
     pilot = plan.read_profile()
     dom = max(pilot, key=lambda k_: pilot[k_][0])
-    # timed region: events only around the dominant kernel's launches (on the launch stream)
-    if args.no_kernel_events:
-        plan.set_profiling(False)
-    else:
+    plan.set_profiling(False)
+
+    # timed region 1 -> `value`: all S lanes in flight
+    elapsed = timed(S, K, W + PILOT)
+
+    # timed region 2 -> `roofline`: ONE lane in flight (kernels do not overlap, so a launch's duration is the kernel's
+    # own), HIP events around the dominant kernel's launches only, on the launch stream
+    if not args.no_kernel_events:
         plan.set_profiling_kernel(dom)
     plan.read_profile()
-
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(K):
-        step(W + PILOT + k)
-    drain()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed_one = timed(1, K, W + PILOT + K)
     prof = plan.read_profile()
     plan.set_profiling(False)
     seam = plan.status(0)
 
-    # single pair in flight (config 2 as a latency figure), untimed by events
+    # single pair in flight (config 2 as a latency figure)
     single_ms = None
     if world == 1 and not args.no_single:
         for k in range(2):
-            step(k, 1)
+            lane_step(0, k, 1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for k in range(5):
-            step(k, 1)
+            lane_step(0, k, 1)
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / 5 * 1e3
 
     if rank == 0:
         mpix_pair = cw * ch / 1e6
-        value = mpix_pair * K * B * world / elapsed
+        value = mpix_pair * K * B * S * world / elapsed
         per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, 4)
         line = {
             "metric": "warp+blend MPix/s at 4096x4096x3 f32", "value": round(value, 2), "unit": "MPix/s",
@@ -219,20 +246,22 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 accumulators)",
             "data": "synthetic",
             "config": {"workload": f"config 2 pairs ({F}x{F}x3 f32 frames -> {cw}x{ch}x3 f32 mosaic: warp + move + "
-                                   f"{plan.levels}-level multi-band blend), {B} independent pairs per GPU per step through one "
-                                   f"launch sequence (config 4's per-GPU shard); canvas pixels counted",
-                       "frame": [F, F, 3], "canvas": [cw, ch, 3], "levels": plan.levels, "pairs_per_gpu_per_step": B,
-                       "pairs_per_step": B * world, "mpix_per_pair": round(mpix_pair, 3),
-                       "ms_per_pair_per_gpu": round(elapsed / K / B * 1e3, 4),
+                                   f"{plan.levels}-level multi-band blend); per GPU per step {S} batches of {B} independent pairs, "
+                                   f"each batch one launch sequence on its own HIP stream (config 4's per-GPU shard); canvas pixels counted",
+                       "frame": [F, F, 3], "canvas": [cw, ch, 3], "levels": plan.levels, "pairs_per_batch": B,
+                       "batches_in_flight": S, "pairs_per_step": B * S * world, "mpix_per_pair": round(mpix_pair, 3),
+                       "ms_per_pair_per_gpu": round(elapsed / K / B / S * 1e3, 4),
+                       "one_batch_in_flight_ms_per_pair": round(elapsed_one / K / B * 1e3, 4),
+                       "one_batch_in_flight_mpix_s": round(mpix_pair * K * B * world / elapsed_one, 1),
                        "single_pair_in_flight_ms": round(single_ms, 4) if single_ms else None,
                        "single_pair_in_flight_mpix_s": round(mpix_pair / single_ms * 1e3, 1) if single_ms else None,
-                       "input_frame_mpix_per_s": round(2 * F * F / 1e6 * K * B * world / elapsed, 2),
+                       "input_frame_mpix_per_s": round(2 * F * F / 1e6 * K * B * S * world / elapsed, 2),
                        "exchange": "none" if world == 1 else "uint8 mosaics all-gathered (RCCL) overlapped with compute",
                        "seam": list(seam.as_tuple())},
         }
         if prof[dom][1] > 0:
             ms, launches, _ = prof[dom]
-            bytes_per_launch = per_kernel[dom] * B * K / launches  # K steps of B pairs were timed
+            bytes_per_launch = per_kernel[dom] * B * K / launches  # region 2: K steps of one batch of B pairs
             avg_s = ms / launches / 1e3
             achieved = bytes_per_launch / avg_s / 1e9
             traffic = None
@@ -249,25 +278,28 @@ def main():
                                 "avg_launch_ms": round(ms / launches, 5), "launches": launches,
                                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                                 "share_of_device_time": round(pilot[dom][0] / pilot_tot, 4),
-                                "note": "average over every launch of this kernel symbol in the timed region (all pyramid levels it runs on); HIP events on the launch stream"}
+                                "note": "timed region 2 (one batch in flight, so launches of different batches do not overlap): average over "
+                                        "every launch of this kernel symbol (all pyramid levels); HIP events on the launch stream"}
         line["kernels"] = {k_: {"ms_per_pair": round(v[0] / PILOT / B, 4), "launches_per_step": v[1] // PILOT,
                                 "level0_ms_per_pair": round(v[2] / PILOT / B, 4),
                                 "algorithmic_GBps": round(per_kernel[k_] / (v[0] / PILOT / B / 1e3) / 1e9, 1) if v[0] > 0 else None}
                            for k_, v in pilot.items()}
-        pair_s = elapsed / K / B
+        pair_s = elapsed / K / B / S
         line["pipeline"] = {"algorithmic_bytes_per_pair": stages["total"], "S1": stages["S1"], "S2": stages["S2"], "S3": stages["S3"],
                             "achieved_GBps_per_gpu": round(stages["total"] / pair_s / 1e9, 1),
                             "frac_of_hbm_peak": round(stages["total"] / pair_s / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_frame, args.verbose)
         print(json.dumps(line), flush=True)
-    if gather is not None and rank == 0 and os.environ.get("STITCH_CHECK_GATHER") == "1":
-        # rehearsal check: the last gathered block holds this rank's own quantised mosaics
-        last = (W + PILOT + K - 1)
-        own = gather.out[last % 2][rank]
-        ok = all(torch.equal(own[q], capi.dev_quantize(outs[last % 2][q])) for q in range(B))
+    if use_dist and rank == 0 and os.environ.get("STITCH_CHECK_GATHER") == "1":
+        # rehearsal check: the last gathered block of lane 0 holds this rank's own quantised mosaics
+        L = lanes[0]
+        last = W + PILOT + 2 * K - 1
+        own = L["gather"].out[last % 2][rank]
+        ok = all(torch.equal(own[q], capi.dev_quantize(L["outs"][last % 2][q])) for q in range(B))
         print(f"[gather check] own mosaics in the gathered block: {'ok' if ok else 'MISMATCH'}", file=sys.stderr)
-    plan.close()
+    for L in lanes:
+        L["plan"].close()
     if use_dist:
         dist.destroy_process_group()
 

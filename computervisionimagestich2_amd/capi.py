@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstitch_hip.so")
+LIB_PATH = os.environ.get("STITCH_LIB", os.path.join(_HERE, "libstitch_hip.so"))  # STITCH_LIB: A/B builds of the same ABI
 
 # kernel ids of stitch_plan_read_profile -> the HIP kernel symbol each one times (rocprofv3 reports the same names)
 KERNELS = ("compose", "seam", "mask", "vv_x_fwd", "vv_x_bwd", "vv_y_fwd", "vv_y_bwd", "decimate", "collapse_top", "collapse",

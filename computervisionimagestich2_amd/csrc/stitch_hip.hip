@@ -268,7 +268,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s) {
             } else
                 HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * np, hipMemcpyDeviceToDevice, s));
             if (do_y) {
-                dim3 g(a.pitch / 64, np);
+                dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
                 {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
                     k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk);

@@ -559,20 +559,22 @@ __device__ __forceinline__ Taps make_taps(int t, int n_src, int n_dst) {
     return r;
 }
 
-// y pass: one column per work-item, so a wavefront reads/writes 256 contiguous bytes of one row per step.
-// The recurrence is cheap next to an HBM round trip, so rows are fetched far ahead of their use: YST stages of
-// YCH rows rotate through registers (YCH*(YST-1) = 24 rows in flight per wavefront while one chunk computes).
-// In place.  grid = (pitch/64, planes).
-constexpr int YCH = 8, YST = 4;
+// y pass: two adjacent columns per work-item (8-byte accesses: a wavefront moves 512 contiguous bytes of one row
+// per step, and the two independent recurrences interleave in the fp64 pipe).  The recurrence is cheap next to an
+// HBM round trip, so rows are fetched far ahead of their use: YST stages of YCH rows rotate through registers
+// (YCH*(YST-1) = 24 rows in flight per wavefront while one chunk computes).  In place.
+// grid = (ceil(pitch/128), planes); pitch is a multiple of 64, a last half-empty block is masked off.
+constexpr int YCH = 8, YST = 4, YCOLS = 2 * WAVE;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Calls f(y, value) for rows y_begin, y_begin +/- 1, ... (count rows), loading each row's value long before.
 template <bool DOWN, typename F>
 __device__ __forceinline__ void stream_rows(const float* __restrict__ p, int pitch, int y_begin, int count, F&& f) {
-    float buf[YST][YCH];
+    f2 buf[YST][YCH];
     // row index is clamped instead of predicated: the tail re-reads the last row, the loop body stays branch-free
     auto ld = [&](int i) {
         const int ic = i < count ? i : count - 1;
-        return p[(size_t)(DOWN ? y_begin + ic : y_begin - ic) * pitch];
+        return *reinterpret_cast<const f2*>(p + (size_t)(DOWN ? y_begin + ic : y_begin - ic) * pitch);
     };
 #pragma unroll
     for (int s = 0; s < YST - 1; ++s)
@@ -605,168 +607,191 @@ __device__ __forceinline__ void stream_rows(const float* __restrict__ p, int pit
     }
 }
 
+// recurrence state of the two columns a work-item owns
+struct Y2 {
+    double a1, a2, a3, b1, b2, b3;
+};
+__device__ __forceinline__ f2 y2_step_fwd(Y2& s, const VVK& k, f2 x) {
+    double a0 = (double)x.x, b0 = (double)x.y;
+    a0 += s.a1 * k.f1;
+    b0 += s.b1 * k.f1;
+    a0 += s.a2 * k.f2;
+    b0 += s.b2 * k.f2;
+    a0 += s.a3 * k.f3;
+    b0 += s.b3 * k.f3;
+    s.a3 = s.a2;
+    s.a2 = s.a1;
+    s.a1 = a0;
+    s.b3 = s.b2;
+    s.b2 = s.b1;
+    s.b1 = b0;
+    f2 r;
+    r.x = (float)a0;
+    r.y = (float)b0;
+    return r;
+}
+__device__ __forceinline__ f2 y2_step_bwd(Y2& s, const VVK& k, f2 x) {
+    double a0 = (double)x.x, b0 = (double)x.y;
+    a0 *= k.sum;
+    b0 *= k.sum;
+    a0 += s.a1 * k.f1;
+    b0 += s.b1 * k.f1;
+    a0 += s.a2 * k.f2;
+    b0 += s.b2 * k.f2;
+    a0 += s.a3 * k.f3;
+    b0 += s.b3 * k.f3;
+    s.a3 = s.a2;
+    s.a2 = s.a1;
+    s.a1 = a0;
+    s.b3 = s.b2;
+    s.b2 = s.b1;
+    s.b1 = b0;
+    f2 r;
+    r.x = (float)a0;
+    r.y = (float)b0;
+    return r;
+}
+// state buffer: [4][planes][pitch] doubles -- v1, v2, v3, iplus of every column
+__device__ __forceinline__ size_t ystate_index(int plane, int pitch, int x) { return (size_t)plane * pitch + x; }
+
 __global__ __launch_bounds__(64) void k_vv_y_fwd(float* __restrict__ data, int h, int pitch, size_t ps, VVK k,
                                                   double* __restrict__ state, MaskL0 mk) {
-    const int x = blockIdx.x * WAVE + threadIdx.x;
+    const int x = (blockIdx.x * WAVE + threadIdx.x) * 2;
+    if (x >= pitch) return;
     float* p = data + blockIdx.y * ps + x;
     // level-0 mask plane: every input row is the one x-blurred row kept in the side buffer (row stride 0)
     const bool side = mk.enabled && (blockIdx.y % 7 == 6);
     const float* src = side ? mk.side + (size_t)(blockIdx.y / 7) * pitch + x : p;
     const int spitch = side ? 0 : pitch;
-    const double iplus = (double)src[(size_t)(h - 1) * spitch];
-    double v1, v2, v3;
-    v1 = v2 = v3 = (double)src[0] / k.sumsq;
-    stream_rows<true>(src, spitch, 0, h, [&](int y, float xv) {
-        double v0 = (double)xv;
-        v0 += v1 * k.f1;
-        v0 += v2 * k.f2;
-        v0 += v3 * k.f3;
-        p[(size_t)y * pitch] = (float)v0;
-        v3 = v2;
-        v2 = v1;
-        v1 = v0;
+    const f2 last = *reinterpret_cast<const f2*>(src + (size_t)(h - 1) * spitch);  // iplus, read before the sweep
+    const f2 x0 = *reinterpret_cast<const f2*>(src);
+    Y2 s;
+    s.a1 = s.a2 = s.a3 = (double)x0.x / k.sumsq;
+    s.b1 = s.b2 = s.b3 = (double)x0.y / k.sumsq;
+    stream_rows<true>(src, spitch, 0, h, [&](int y, f2 xv) {
+        *reinterpret_cast<f2*>(p + (size_t)y * pitch) = y2_step_fwd(s, k, xv);
     });
-    const size_t n = (size_t)gridDim.x * WAVE * gridDim.y, i = (size_t)blockIdx.y * gridDim.x * WAVE + x;
-    state[i] = v1;
-    state[n + i] = v2;
-    state[2 * n + i] = v3;
-    state[3 * n + i] = iplus;
+    const size_t n = (size_t)gridDim.y * pitch, i = ystate_index(blockIdx.y, pitch, x);
+    state[i] = s.a1;
+    state[i + 1] = s.b1;
+    state[n + i] = s.a2;
+    state[n + i + 1] = s.b2;
+    state[2 * n + i] = s.a3;
+    state[2 * n + i + 1] = s.b3;
+    state[3 * n + i] = (double)last.x;
+    state[3 * n + i + 1] = (double)last.y;
 }
 
-// Anticausal y pass, stand-alone (odd source widths, Deriche-free fallback): stores the blurred rows in place.
+__device__ __forceinline__ void y2_triggs(const VVK& k, const double* __restrict__ state, size_t n, size_t i, Y2& s, f2& first) {
+    float fa, fb;
+    s.a1 = state[i];
+    s.a2 = state[n + i];
+    s.a3 = state[2 * n + i];
+    triggs(k, state[3 * n + i], s.a1, s.a2, s.a3, fa);
+    s.b1 = state[i + 1];
+    s.b2 = state[n + i + 1];
+    s.b3 = state[2 * n + i + 1];
+    triggs(k, state[3 * n + i + 1], s.b1, s.b2, s.b3, fb);
+    first.x = fa;
+    first.y = fb;
+}
+
+// Anticausal y pass, stand-alone (odd source widths): stores the blurred rows in place.
 __global__ __launch_bounds__(64) void k_vv_y_bwd(float* __restrict__ data, int h, int pitch, size_t ps, VVK k,
                                                   const double* __restrict__ state) {
-    const int x = blockIdx.x * WAVE + threadIdx.x;
+    const int x = (blockIdx.x * WAVE + threadIdx.x) * 2;
+    if (x >= pitch) return;
     float* p = data + blockIdx.y * ps + x;
-    const size_t n = (size_t)gridDim.x * WAVE * gridDim.y, i = (size_t)blockIdx.y * gridDim.x * WAVE + x;
-    double v1 = state[i], v2 = state[n + i], v3 = state[2 * n + i];
-    const double iplus = state[3 * n + i];
-    float first;
-    triggs(k, iplus, v1, v2, v3, first);
-    p[(size_t)(h - 1) * pitch] = first;
-    stream_rows<false>(p, pitch, h - 2, h - 1, [&](int y, float xv) {
-        double v0 = (double)xv;
-        v0 *= k.sum;
-        v0 += v1 * k.f1;
-        v0 += v2 * k.f2;
-        v0 += v3 * k.f3;
-        v3 = v2;
-        v2 = v1;
-        v1 = v0;
-        p[(size_t)y * pitch] = (float)v0;
+    Y2 s;
+    f2 first;
+    y2_triggs(k, state, (size_t)gridDim.y * pitch, ystate_index(blockIdx.y, pitch, x), s, first);
+    *reinterpret_cast<f2*>(p + (size_t)(h - 1) * pitch) = first;
+    stream_rows<false>(p, pitch, h - 2, h - 1, [&](int y, f2 xv) {
+        *reinterpret_cast<f2*>(p + (size_t)y * pitch) = y2_step_bwd(s, k, xv);
     });
 }
 
 // Anticausal y pass fused with the decimation (even source width): the blurred level is never written.
-// A lone wavefront is bound by its own instruction issue (recurrence + two IEEE divides per sample), so the
-// work is split over the two wavefronts of a workgroup:
-//   wave 0 (producer)  runs the recurrence for 64 columns, rows bottom-up, and drops each blurred row into an
-//                      LDS ring (two slots of YCH rows);
-//   wave 1 (consumer)  takes the rows two at a time -- lanes 0-31 own the 32 column pairs of the upper row,
-//                      lanes 32-63 those of the lower row -- x-decimates them (columns 2t, 2t+1, both overlaps
-//                      = w2, CImg.h:29542-29555: acc = 0; acc += s0*d; acc += s1*d; acc /= W), then lanes 0-31
-//                      y-decimate (CImg.h:29557-29575: accumulation in INCREASING source row although rows arrive
-//                      bottom-up; overlaps {h2,h2} for even h, {h2-t, h2, t+1} for odd h) and store 128 bytes
-//                      of the next pyramid level.
+// A lone wavefront is bound by its own instruction issue (recurrence + IEEE divides), so the work is split over
+// the two wavefronts of a workgroup:
+//   wave 0 (producer)  runs the recurrence for 128 columns (two per lane), rows bottom-up, and drops each blurred
+//                      row into an LDS ring (two slots of YCH rows);
+//   wave 1 (consumer)  owns one column PAIR per lane: x-decimates each row (columns 2t, 2t+1, both overlaps = w2,
+//                      CImg.h:29542-29555: acc = 0; acc += s0*d; acc += s1*d; acc /= W), keeps the last two
+//                      x-decimated rows, and for every output row y-decimates (CImg.h:29557-29575: accumulation in
+//                      INCREASING source row although rows arrive bottom-up; overlaps {h2,h2} for even h,
+//                      {h2-t, h2, t+1} for odd h) and stores 256 bytes of the next pyramid level.
 // One workgroup barrier per YCH rows hands a slot over.  rc = h-1-y counts rows in processing order.
 __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ data, int w, int h, int pitch, size_t ps,
                                                       VVK k, const double* __restrict__ state, float* __restrict__ dst,
                                                       int w2, int h2, int dpitch, size_t dps) {
-    __shared__ __attribute__((aligned(16))) float ring[2][YCH][WAVE];
+    __shared__ __attribute__((aligned(16))) float ring[2][YCH][YCOLS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nchunks = (h + YCH - 1) / YCH;
-    // producer state
-    const int x = blockIdx.x * WAVE + lane;
-    const float* p = data + blockIdx.y * ps + x;
-    double v1 = 0, v2 = 0, v3 = 0;
-    float first = 0.f;
-    float buf[YST][YCH];
+    const int x = (blockIdx.x * WAVE + lane) * 2;  // first of this lane's two columns
+    const bool col_live = x < pitch;
+    const float* p = data + blockIdx.y * ps + (col_live ? x : 0);
+    Y2 s{};
+    f2 first{};
+    f2 buf[YST][YCH];
     auto ld = [&](int rc) {
         const int r = rc < h ? rc : h - 1;
-        return p[(size_t)(h - 1 - r) * pitch];
+        return *reinterpret_cast<const f2*>(p + (size_t)(h - 1 - r) * pitch);
     };
     if (wave == 0) {
-        const size_t n = (size_t)gridDim.x * WAVE * gridDim.y, i = (size_t)blockIdx.y * gridDim.x * WAVE + x;
-        v1 = state[i];
-        v2 = state[n + i];
-        v3 = state[2 * n + i];
-        triggs(k, state[3 * n + i], v1, v2, v3, first);
+        if (col_live) y2_triggs(k, state, (size_t)gridDim.y * pitch, ystate_index(blockIdx.y, pitch, x), s, first);
 #pragma unroll
-        for (int s = 0; s < YST - 1; ++s)
+        for (int st = 0; st < YST - 1; ++st)
 #pragma unroll
-            for (int u = 0; u < YCH; ++u) buf[s][u] = ld(s * YCH + u);
+            for (int u = 0; u < YCH; ++u) buf[st][u] = ld(st * YCH + u);
     }
-    // consumer state
+    // consumer state: this lane's output column t_x = x/2
     const float fsx = (float)(unsigned)w2, fw = (float)(unsigned)w, fh = (float)(unsigned)h, fsy = (float)(unsigned)h2;
     const bool h_odd = (h & 1) != 0;
-    const int half = lane >> 5, cp = lane & 31;
-    float* drow = dst + blockIdx.y * dps + (blockIdx.x * (WAVE / 2) + cp);
-    const bool dst_live = half == 0 && (blockIdx.x * (WAVE / 2) + cp) < w2;
-    float pXlo = 0.f, pXhi = 0.f;  // previous pair (odd h only), valid in lanes 0-31
+    const int tx = blockIdx.x * WAVE + lane;
+    float* dcol = dst + blockIdx.y * dps + tx;
+    const bool dst_live = tx < w2;
+    float Xp1 = 0.f, Xp2 = 0.f;  // x-decimated rows y+1 and y+2 (previous two rows in processing order)
 
     for (int j0 = 0; j0 <= nchunks; j0 += YST) {
 #pragma unroll
-        for (int s = 0; s < YST; ++s) {
-            const int j = j0 + s;
+        for (int st = 0; st < YST; ++st) {
+            const int j = j0 + st;
             if (wave == 0) {
 #pragma unroll
-                for (int u = 0; u < YCH; ++u) buf[(s + YST - 1) % YST][u] = ld((j + YST - 1) * YCH + u);
+                for (int u = 0; u < YCH; ++u) buf[(st + YST - 1) % YST][u] = ld((j + YST - 1) * YCH + u);
                 if (j < nchunks) {
 #pragma unroll
                     for (int u = 0; u < YCH; ++u) {
                         const int rc = j * YCH + u;
-                        float o;
-                        if (rc == 0) {
-                            o = first;  // sample h-1 takes the Triggs boundary value (CImg.h:34920)
-                        } else {
-                            double v0 = (double)buf[s][u];
-                            v0 *= k.sum;
-                            v0 += v1 * k.f1;
-                            v0 += v2 * k.f2;
-                            v0 += v3 * k.f3;
-                            v3 = v2;
-                            v2 = v1;
-                            v1 = v0;
-                            o = (float)v0;
-                        }
-                        ring[s & 1][u][lane] = o;  // rows rc >= h of the last chunk are never read
+                        // sample h-1 takes the Triggs boundary value (CImg.h:34920); rows rc >= h are never read
+                        const f2 o = rc == 0 ? first : y2_step_bwd(s, k, buf[st][u]);
+                        *reinterpret_cast<f2*>(&ring[st & 1][u][2 * lane]) = o;
                     }
                 }
             } else if (j >= 1 && j - 1 < nchunks) {
                 const int jc = j - 1;
 #pragma unroll
-                for (int u = 0; u < YCH; u += 2) {
-                    const int rc_lo = jc * YCH + u;  // upper row of the pair (y = h-1-rc_lo), lower row is rc_lo+1
-                    if (rc_lo < h) {
-                        const float2 v = *reinterpret_cast<const float2*>(&ring[(s + 1) & 1][u + half][2 * cp]);
+                for (int u = 0; u < YCH; ++u) {
+                    const int rc = jc * YCH + u;
+                    if (rc < h) {
+                        const int y = h - 1 - rc;
+                        const f2 v = *reinterpret_cast<const f2*>(&ring[(st + 1) & 1][u][2 * lane]);
                         float X = 0.f;
                         X += v.x * fsx;
                         X += v.y * fsx;
                         X /= fw;
-                        const float Xhi = __shfl_down(X, 32, 64);  // lanes 0-31: lower row's pair
-                        const int m = rc_lo >> 1;
-                        if (!h_odd) {
-                            // rows (2t+1, 2t) with t = h2-1-m
+                        if ((y & 1) == 0 && (y >> 1) < h2) {  // row y = 2t completes output row t
+                            const int t = y >> 1;
                             float a2 = 0.f;
-                            a2 += Xhi * fsy;
-                            a2 += X * fsy;
+                            a2 += X * (h_odd ? (float)(unsigned)(h2 - t) : fsy);
+                            a2 += Xp1 * fsy;
+                            if (h_odd) a2 += Xp2 * (float)(unsigned)(t + 1);
                             a2 /= fh;
-                            if (dst_live) drow[(size_t)(h2 - 1 - m) * dpitch] = a2;
-                        } else {
-                            // pair m = rows (2*h2-2m, 2*h2-2m-1); output t = h2-m needs rows 2t (= this upper row),
-                            // 2t+1 and 2t+2 (= previous pair's lower and upper rows)
-                            if (m >= 1) {
-                                const int t = h2 - m;
-                                float a2 = 0.f;
-                                a2 += X * (float)(unsigned)(h2 - t);
-                                a2 += pXhi * fsy;
-                                a2 += pXlo * (float)(unsigned)(t + 1);
-                                a2 /= fh;
-                                if (dst_live) drow[(size_t)t * dpitch] = a2;
-                            }
-                            pXlo = X;
-                            pXhi = Xhi;
+                            if (dst_live) dcol[(size_t)t * dpitch] = a2;
                         }
+                        Xp2 = Xp1;
+                        Xp1 = X;
                     }
                 }
             }
@@ -913,7 +938,10 @@ struct OutPtrs {
 // and consecutive output rows share their source rows (iy advances by at most one per output row when
 // up-sampling), so the x-interpolated values of the two current source rows are kept in registers and only a newly
 // entered source row is interpolated: the double-precision work per pixel halves, the values are the same floats.
-constexpr int CROWS = 8;
+#ifndef STITCH_CROWS
+#define STITCH_CROWS 8
+#endif
+constexpr int CROWS = STITCH_CROWS;
 template <typename OUT, bool DENSE>
 __global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_all, int w, int h, int pitch, size_t ps,
                                                   const float* __restrict__ gn_all, const float* __restrict__ en_all, int sw,
