@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-steps_total = int(sys.argv[3]) if len(sys.argv) > 3 else 6  # warmup 1 + pilot 3 + timed 2 of scripts/pmc.sh
+steps_total = None  # derived below: k_compose runs once per step
 
 GROUP = {"k_compose": "compose", "k_seam": "seam", "k_mask": "mask", "k_vv_x_fwd": "vv_x_fwd",
          "k_vv_x_bwd": "vv_x_bwd", "k_vv_y_fwd": "vv_y_fwd", "k_vv_y_bwd_dec": "vv_y_bwd", "k_vv_y_bwd": "vv_y_bwd",
@@ -40,12 +40,16 @@ def counter(name):
     f = glob.glob(os.path.join(src, name, "runc", "*counter_collection.csv"))[0]
     tot = collections.defaultdict(float)
     mx = collections.defaultdict(float)
+    cnt = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != name:
             continue
         k = kname(r["Kernel_Name"])
         tot[k] += float(r["Counter_Value"])
         mx[k] = max(mx[k], float(r["Counter_Value"]))
+        cnt[k] += 1
+    global steps_total
+    steps_total = cnt.get("k_compose", 0) or steps_total
     return tot, mx
 
 
