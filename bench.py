@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- warp+blend MPix/s at 4096x4096x3 f32 (BASELINE.json), one process per GPU.
 
-A step = one pass of the hot path (warp + move + multi-band blend) over synthetic input: --streams (default 2)
-batches of --batch (default 4) independent config-2 pairs per rank (two 4096x4096x3 f32 frames -> 6144x4096x3 f32
+A step = one pass of the hot path (warp + move + multi-band blend) over synthetic input: --streams (default 3)
+batches of --batch (default 3) independent config-2 pairs per rank (two 4096x4096x3 f32 frames -> 6144x4096x3 f32
 mosaic each; pair i of the config-4 family has p[3] = -2048 - 8i); a batch is ONE launch sequence of a batched plan
 on its own HIP stream.  Frames are generated on the device before the timed
 region, so every input is resident in HBM when timing starts.  Pairs are independent: no data-path collective;
@@ -32,8 +32,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="independent pairs per batch (one launch sequence)")
-    ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU, each on its own HIP stream")
+    ap.add_argument("--batch", type=int, default=3, help="independent pairs per batch (one launch sequence)")
+    ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU, each on its own HIP stream")
     ap.add_argument("--frame", type=int, default=4096, help="frame edge (4096 = the metric's configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frame", type=int, default=4096, help="frame edge of the CPU baseline's bounded sample")
@@ -239,7 +239,7 @@ def main():
     if rank == 0:
         mpix_pair = cw * ch / 1e6
         value = mpix_pair * K * B * S * world / elapsed
-        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, 4)
+        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, 4, plan.fused_sweep_levels)
         line = {
             "metric": "warp+blend MPix/s at 4096x4096x3 f32", "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
@@ -249,7 +249,7 @@ def main():
                                    f"{plan.levels}-level multi-band blend); per GPU per step {S} batches of {B} independent pairs, "
                                    f"each batch one launch sequence on its own HIP stream (config 4's per-GPU shard); canvas pixels counted",
                        "frame": [F, F, 3], "canvas": [cw, ch, 3], "levels": plan.levels, "pairs_per_batch": B,
-                       "batches_in_flight": S, "pairs_per_step": B * S * world, "mpix_per_pair": round(mpix_pair, 3),
+                       "batches_in_flight": S, "fused_sweep_levels": plan.fused_sweep_levels, "pairs_per_step": B * S * world, "mpix_per_pair": round(mpix_pair, 3),
                        "ms_per_pair_per_gpu": round(elapsed / K / B / S * 1e3, 4),
                        "one_batch_in_flight_ms_per_pair": round(elapsed_one / K / B * 1e3, 4),
                        "one_batch_in_flight_mpix_s": round(mpix_pair * K * B * world / elapsed_one, 1),

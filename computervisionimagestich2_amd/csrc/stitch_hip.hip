@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -165,6 +166,8 @@ struct Level {
     double *ax, *ay;
 };
 
+constexpr int WF_CTRL_WORDS = 4 * 16 + 16;  // band-queue heads of up to 4 levels (64 bytes apart) + the abort word
+
 struct ProfRec {
     int stage, level;
     hipEvent_t a, b;
@@ -184,6 +187,14 @@ struct stitch_plan {
     float* T = nullptr;   // blur scratch, 7 planes of level 0 + slack
     float* T2 = nullptr;  // Deriche temporaries (blur_kind 1 only)
     double* state = nullptr;
+    // fused anticausal-x + causal-y wavefront sweep (k_vv_xbyf) for the first `wf_levels` levels
+    int wf_levels = 0;
+    u64* wf_yg = nullptr;
+    size_t wf_yg_bytes = 0;
+    unsigned* wf_ctrl = nullptr;   // per level one band-queue head (16 words apart), then the abort flag
+    unsigned wf_epoch = 0;
+    unsigned long long* wf_dbg = nullptr;  // STITCH_WAVEFRONT_STAMP=1: [2048][8] segment cycle sums (diagnostics)
+    unsigned* h_wf_abort = nullptr;  // pinned copy of the abort flag of the last call
     float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
     bool mask_opt = false;  // level-0 mask handled implicitly (Van Vliet, level-0 height a multiple of 64)
     SeamDev* d_seam = nullptr;
@@ -241,6 +252,7 @@ int launch_check(const char* what) {
 // REDUCE for every level (ImageProcess.cpp:705-715): blur(G_l) into T, decimate T into G_{l+1}.
 int run_reduce(stitch_plan* p, int n, hipStream_t s) {
     const int np = 7 * n;  // planes in flight: every launch covers all pairs of the batch
+    if (p->wf_levels > 0) HIPCHK(hipMemsetAsync(p->wf_ctrl, 0, sizeof(unsigned) * WF_CTRL_WORDS, s));  // tile-queue heads + abort flag
     for (int l = 0; l + 1 < p->L; ++l) {
         const Level& a = p->lv[l];
         const Level& b = p->lv[l + 1];
@@ -254,7 +266,46 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s) {
             mk.h = a.h;
             mk.enabled = 1;
         }
-        if (p->opts.blur_kind == 0) {
+        const bool wavefront = p->opts.blur_kind == 0 && do_x && do_y && l < p->wf_levels;
+        if (wavefront) {
+            const int nb = (int)((lines + TS - 1) / TS);
+            {
+                StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
+                k_vv_x_fwd<<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk);
+            }
+            Wavefront wf{};
+            wf.yg = p->wf_yg;
+            wf.counter = p->wf_ctrl + (size_t)l * 16;
+            wf.abort = p->wf_ctrl + WF_CTRL_WORDS - 16;
+            wf.NR = (a.h + TS - 1) / TS;
+            wf.NC = (a.w + TS - 1) / TS;
+            wf.NP = np;
+            if (++p->wf_epoch > 0xFFFFEu) {  // tags would repeat: clear the granules and start over
+                HIPCHK(hipMemsetAsync(p->wf_yg, 0, p->wf_yg_bytes, s));
+                p->wf_epoch = 1;
+            }
+            wf.epoch = p->wf_epoch;
+            wf.mask_l0 = mk.enabled;
+            const long ntiles = (long)wf.NP * wf.NR;  // one persistent wavefront per row band
+            // the x-sweep state lives in state[0 .. 4*lines); the y state the kernel leaves goes behind it
+            double* state_y = p->state + 4 * (size_t)p->cap * 7 * (a.h + 64);
+            {
+                StageTimer t(p, s, STITCH_K_VV_XBYF, l);
+                const int wg = (int)std::min<long>(ntiles, 2304);  // 9 workgroups per CU by LDS
+                if (p->wf_dbg && l == 0) {  // diagnostic build: per-segment cycle sums of the level-0 launch
+                    wf.dbg = p->wf_dbg;
+                    k_vv_xbyf<true><<<wg, 64, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf);
+                } else
+                    k_vv_xbyf<false><<<wg, 64, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf);
+            }
+            StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
+            dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
+            if ((a.w & 1) == 0 && !p->no_fuse) {
+                k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps);
+                decimated = true;
+            } else
+                k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, state_y);
+        } else if (p->opts.blur_kind == 0) {
             if (do_x) {
                 const int nb = (int)((lines + TS - 1) / TS);
                 {
@@ -297,6 +348,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s) {
             k_decimate<<<grid_xy(b.pitch, b.h, np), 256, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, b.g, b.w, b.h, b.pitch, b.ps);
         }
     }
+    if (p->wf_levels > 0) HIPCHK(hipMemcpyAsync(p->h_wf_abort, p->wf_ctrl + WF_CTRL_WORDS - 16, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     return launch_check("reduce");
 }
 
@@ -801,7 +853,20 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     const size_t t_bytes = sizeof(float) * (v0.ps * 7 * B + (size_t)v0.pitch * 64);
     const size_t t_off = take(t_bytes);
     const size_t t2_off = o.blur_kind == 1 ? take(t_bytes) : 0;
-    const size_t state_n = 4 * 7 * B * (size_t)std::max(v0.h + 64, v0.pitch);
+    // wavefront sweep: enabled with STITCH_WAVEFRONT=<levels> (Van Vliet only); granule buffers sized for level 0
+    int wf_levels = 0;
+    if (const char* e = std::getenv("STITCH_WAVEFRONT"))
+        wf_levels = std::max(0, std::min(4, std::atoi(e)));
+    else  // auto: the band pipeline pays where a level has many bands and tiles to stream (fill = bands x hand-off)
+        while (wf_levels < 2 && wf_levels < L - 1 && lw[wf_levels] >= 1024 && lh[wf_levels] >= 1024) ++wf_levels;
+    if (o.blur_kind != 0 || std::getenv("STITCH_NO_FUSE") || o.sigma < 0.5f) wf_levels = 0;
+    wf_levels = std::min(wf_levels, L - 1);
+    while (wf_levels > 0 && (lw[wf_levels - 1] < 2 || lh[wf_levels - 1] < 2)) --wf_levels;
+    const int NC0 = (v0.w + TS - 1) / TS;
+    const size_t yg_off = wf_levels ? take(sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE) : 0;
+    const size_t wfc_off = wf_levels ? take(sizeof(unsigned) * WF_CTRL_WORDS) : 0;
+    // x-sweep state [4][lines] followed by the y state the wavefront kernel leaves [4][planes][pitch]
+    const size_t state_n = 4 * 7 * B * (size_t)(v0.h + 64) + 4 * 7 * B * (size_t)std::max(v0.h + 64, v0.pitch);
     const size_t st_off = take(sizeof(double) * state_n);
     const size_t seam_off = take(sizeof(SeamDev) * B);
     const size_t side_off = take(sizeof(float) * B * v0.pitch);
@@ -827,6 +892,15 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     p->T2 = o.blur_kind == 1 ? reinterpret_cast<float*>(base + t2_off) : nullptr;
     p->state = reinterpret_cast<double*>(base + st_off);
     p->d_seam = reinterpret_cast<SeamDev*>(base + seam_off);
+    p->wf_levels = wf_levels;
+    if (wf_levels && std::getenv("STITCH_WAVEFRONT_STAMP")) {
+        if (hipMalloc((void**)&p->wf_dbg, sizeof(unsigned long long) * 2304 * 8) != hipSuccess) p->wf_dbg = nullptr;
+    }
+    if (wf_levels) {
+        p->wf_yg = reinterpret_cast<u64*>(base + yg_off);
+        p->wf_yg_bytes = sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE;
+        p->wf_ctrl = reinterpret_cast<unsigned*>(base + wfc_off);
+    }
     p->side = reinterpret_cast<float*>(base + side_off);
     // implicit level-0 mask: needs both Van Vliet sweeps at level 0 and 64-row blocks that do not straddle planes
     p->mask_opt = !p->no_fuse && o.blur_kind == 0 && !p->blur_skip && L >= 2 && v0.w > 1 && v0.h > 1 && (v0.h % 64) == 0;
@@ -851,6 +925,13 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         }
     }
     std::memset(p->h_seam, 0, sizeof(SeamDev) * B);
+    if (wf_levels) {
+        if (hipHostMalloc((void**)&p->h_wf_abort, sizeof(unsigned)) != hipSuccess) {
+            stitch_plan_destroy(p);
+            return fail(STITCH_ERR_HIP, "plan_create: pinned allocation failed");
+        }
+        *p->h_wf_abort = 0;
+    }
     *plan_out = p;
     return STITCH_OK;
 }
@@ -866,6 +947,22 @@ void stitch_plan_destroy(stitch_plan* p) {
     for (auto e : p->free_events) (void)hipEventDestroy(e);
     if (p->arena) (void)hipFree(p->arena);
     if (p->h_seam) (void)hipHostFree(p->h_seam);
+    if (p->h_wf_abort) (void)hipHostFree(p->h_wf_abort);
+    if (p->wf_dbg) {
+        std::vector<unsigned long long> hsum(2304 * 8);
+        if (hipMemcpy(hsum.data(), p->wf_dbg, sizeof(unsigned long long) * 2304 * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double tot[8] = {0};
+            for (int i = 0; i < 2304; ++i)
+                for (int j = 0; j < 8; ++j) tot[j] += (double)hsum[i * 8 + j];
+            static const char* nm[8] = {"claim", "tile-fetch", "x-sweep", "y-wait", "y-sweep", "store", "-", "-"};
+            double all = 0;
+            for (int j = 0; j < 6; ++j) all += tot[j];
+            std::fprintf(stderr, "[wavefront stamps, last level-0 launch, share of workgroup time]");
+            for (int j = 0; j < 6; ++j) std::fprintf(stderr, " %s %.1f%%", nm[j], 100.0 * tot[j] / all);
+            std::fprintf(stderr, " | mean cycles per workgroup %.0f\n", all / 2304);
+        }
+        (void)hipFree(p->wf_dbg);
+    }
     delete p;
 }
 
@@ -902,6 +999,7 @@ int stitch_plan_status_at(stitch_plan* p, int index, stitch_seam* seam_out) {
         HIPCHK(hipStreamSynchronize(p->last_stream));
         p->pending = false;
     }
+    if (p->h_wf_abort && *p->h_wf_abort) return fail(STITCH_ERR_HIP, "wavefront sweep timed out waiting for a neighbouring tile (results are invalid)");
     const SeamDev& sd = p->h_seam[index];
     seam_to_public(sd, seam_out);
     if (sd.status == -2) return fail(STITCH_ERR_EMPTY_MIDROW, "blend: channel 0 of a's middle row is empty (pair %d)", index);
@@ -912,6 +1010,7 @@ int stitch_plan_status_at(stitch_plan* p, int index, stitch_seam* seam_out) {
 int stitch_plan_status(stitch_plan* p, stitch_seam* seam_out) { return stitch_plan_status_at(p, 0, seam_out); }
 
 int stitch_plan_capacity(const stitch_plan* p) { return p ? p->cap : 0; }
+int stitch_plan_fused_sweep_levels(const stitch_plan* p) { return p ? p->wf_levels : 0; }
 
 int stitch_dev_pairs_u8(stitch_plan* plan, const stitch_pair_desc* pairs, int n, void* stream) {
     return dev_pairs<uint8_t>(plan, pairs, n, stream);

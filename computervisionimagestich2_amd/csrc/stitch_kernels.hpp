@@ -355,6 +355,15 @@ __device__ __forceinline__ float mask_step(const SeamDev& sd, int x) {
     return sd.branch == 0 ? ((double)x < sd.thr ? 1.f : 0.f) : (x >= sd.start ? 1.f : 0.f);
 }
 
+__device__ __forceinline__ void tile_store_rows(float* __restrict__ base, int pitch, int c0, int lane, const float* tile, int nrows) {
+    float* p = base + (size_t)(lane >> 4) * pitch + c0 + ((lane & 15) << 2);
+    const float* t = tile + (lane >> 4) * TP + ((lane & 15) << 2);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if ((lane >> 4) + 4 * i < nrows)
+            *reinterpret_cast<f4*>(p + (size_t)(4 * i) * pitch) = *reinterpret_cast<const f4*>(t + (4 * i) * TP);
+}
+
 // `lines` = rows of all planes stacked (plane stride = pitch*h, so line L starts at L*pitch); the buffers are
 // allocated with 64 spare rows so that a partial last block may touch rows >= lines without leaving them.
 __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, float* __restrict__ out, int w, int pitch,
@@ -798,6 +807,247 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
             __syncthreads();
         }
     }
+}
+
+// ---- fused anticausal-x + causal-y sweep: row bands as pipeline stages ---------------------------------------
+// The anticausal x sweep walks a row right-to-left, the causal y sweep walks a column top-down.  One wavefront owns
+// a 64-row band of one plane and walks it right-to-left in 64x64 tiles: each tile is fetched to LDS, swept along x
+// (lane = row; the x state never leaves the registers), then along y (lane = column) and written back once -- the
+// level is read and written ONCE instead of twice.  The y sweep of tile (R,C) needs the y state of the 64 columns
+// as band R-1 left it, so band R simply runs a constant lag (one y sweep + one hand-off) behind band R-1: all
+// bands of all planes are in flight at once, a 64-deep software pipeline per plane.  The per-sample arithmetic and
+// its order are those of k_vv_x_bwd / k_vv_y_fwd.
+//
+// Workgroups are persistent and claim bands in increasing R from one atomic counter, so the band a claimed band
+// depends on has always been claimed earlier by a workgroup that is running (no residency assumption, no deadlock).
+// The y state travels as 8-byte {tag, word} granules (the data is the flag; relaxed agent-scope atomics = sc1
+// write-through stores / L1-bypassing loads; guide 6, Guideline 16, form R2): six granules per lane for three
+// doubles.  tag = (launch epoch << 12) | (producer band + 1), so the slot of a column block is reused band after
+// band and never has to be cleared.  Every spin is bounded; a timeout raises `abort` for all workgroups.
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+struct Wavefront {
+    u64* yg;            // [planes][NC][7][64] granules: y state leaving band R towards band R+1 (+ one spare word)
+    int mask_l0;        // level-0 implicit mask (see MaskL0): planes p%7==6 carry their x-blurred row in the 7th granule
+    unsigned* counter;  // band queue head (zeroed by the host before the launch)
+    unsigned* abort;    // set when a spin timed out
+    int NR, NC, NP;
+    unsigned epoch;
+    unsigned long long* dbg;  // diagnostic build only: [workgroups][8] cycle sums per segment
+};
+
+constexpr int WF_GRAN = 7;  // granules per lane and slot: 3 doubles = 6 words, + 1 spare word
+__device__ __forceinline__ void granules_publish(u64* base, int lane, unsigned tag, double a, double b, double c, unsigned extra) {
+    const u64 w[3] = {(u64)__double_as_longlong(a), (u64)__double_as_longlong(b), (u64)__double_as_longlong(c)};
+    __hip_atomic_store((gu64*)(base + 6 * WAVE + lane), ((u64)tag << 32) | extra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        __hip_atomic_store((gu64*)(base + (2 * i) * WAVE + lane), ((u64)tag << 32) | (w[i] & 0xffffffffu), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((gu64*)(base + (2 * i + 1) * WAVE + lane), ((u64)tag << 32) | (w[i] >> 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// Wait for a state.  Pollers cost the streaming wavefronts bandwidth (guide, "polling-cost"), and most bands wait
+// long for their first tile (band R starts R hand-offs after band 0), so the wait is two-phase: ONE lane re-reads
+// ONE granule with a long sleep between polls; once its tag matches, the whole wavefront reads its six granules,
+// repeating that (rarely) until every tag matches -- the stores of one publish may become visible in any order.
+// Wave-uniform exit; false on timeout / abort.
+__device__ __forceinline__ bool granules_consume(const u64* base, int lane, unsigned tag, unsigned* abort, double& a, double& b,
+                                                 double& c, unsigned& extra) {
+    for (unsigned spins = 0;; ++spins) {
+        unsigned seen = 0;
+        if (lane == 0)
+            seen = (unsigned)(__hip_atomic_load((gu64*)(base + 5 * WAVE + (WAVE - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+        seen = __shfl(seen, 0, 64);
+        if (seen == tag) {
+            u64 g[WF_GRAN];
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < WF_GRAN; ++i) {
+                g[i] = __hip_atomic_load((gu64*)(base + i * WAVE + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok &= (unsigned)(g[i] >> 32) == tag;
+            }
+            if (__all(ok)) {
+                extra = (unsigned)g[6];
+                a = __longlong_as_double((long long)((g[0] & 0xffffffffu) | (g[1] << 32)));
+                b = __longlong_as_double((long long)((g[2] & 0xffffffffu) | (g[3] << 32)));
+                c = __longlong_as_double((long long)((g[4] & 0xffffffffu) | (g[5] << 32)));
+                return true;
+            }
+        } else {
+            if ((spins & 31) == 31) {
+                unsigned ab = 0;
+                if (lane == 0) ab = __hip_atomic_load((gu32*)abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ab = __shfl(ab, 0, 64);
+                if (ab != 0 || spins > (1u << 20)) {
+                    if (lane == 0) __hip_atomic_store((gu32*)abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w, int h, int pitch, VVK k,
+                                                 const double* __restrict__ state_x, long lines, double* __restrict__ state_y,
+                                                 Wavefront wf) {
+    __shared__ __attribute__((aligned(16))) float tile[TS * TP];
+    const int lane = threadIdx.x;
+    const unsigned nbands = (unsigned)wf.NP * wf.NR;
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    auto stamp = [&](int i) {
+        if (STAMP) {
+            t1 = __builtin_amdgcn_s_memtime();
+            seg[i] += t1 - t0;
+            t0 = t1;
+        }
+    };
+    if (STAMP) t0 = __builtin_amdgcn_s_memtime();
+    bool dead = false;
+    while (!dead) {
+        unsigned q = 0;
+        if (lane == 0) q = atomicAdd(wf.counter, 1u);
+        q = __shfl(q, 0, 64);
+        if (q >= nbands) break;
+        const int R = (int)(q / wf.NP), p = (int)(q % wf.NP);  // every plane's band R before any band R+1
+        const int r0 = R * TS, nrows = min(TS, h - r0);
+        float* base = data + ((size_t)p * h + r0) * pitch;
+        // level-0 implicit mask plane below its first band: every row equals the x-blurred row that band 0 passes down
+        // with the y state, so there is nothing to fetch and no x sweep to run (k_vv_x_fwd skipped these rows too)
+        const bool const_rows = wf.mask_l0 && (p % 7 == 6) && R > 0;
+        const bool pass_row = wf.mask_l0 && (p % 7 == 6);
+        stamp(0);  // claim
+
+        // x state of this band's rows: where the causal x sweep left it, through the Triggs boundary (CImg.h:34911-34922)
+        double v1 = 0, v2 = 0, v3 = 0;
+        float first;
+        {
+            const long line = (long)p * h + r0 + lane;
+            double iplus = 0;
+            if (lane < nrows) {
+                v1 = state_x[line];
+                v2 = state_x[lines + line];
+                v3 = state_x[2 * lines + line];
+                iplus = state_x[3 * lines + line];
+            }
+            triggs(k, iplus, v1, v2, v3, first);
+        }
+        f4 pre[16];
+        if (!const_rows) tile_load(base, pitch, (wf.NC - 1) * TS, lane, pre);
+        for (int C = wf.NC - 1; C >= 0; --C) {
+            const int c0 = C * TS, ncols = min(TS, w - c0);
+            if (!const_rows) {
+                tile_to_lds(tile, lane, pre);
+                if (C > 0) tile_load(base, pitch, c0 - TS, lane, pre);  // next tile of the band, in flight during both sweeps
+            }
+            __syncthreads();
+            stamp(1);  // tile fetch
+            // ---- anticausal x sweep, lane = row r0+lane ---------------------------------------------------------
+            if (!const_rows) {
+                float* row = tile + lane * TP;
+                int jtop = ncols;
+                if (C == wf.NC - 1) {
+                    row[jtop - 1] = first;  // sample w-1 takes the boundary value (CImg.h:34920)
+                    --jtop;
+                }
+                const int jfull = jtop & ~15;
+                for (int j = jtop - 1; j >= jfull; --j) {
+                    double v0 = (double)row[j];
+                    v0 *= k.sum;
+                    v0 += v1 * k.f1;
+                    v0 += v2 * k.f2;
+                    v0 += v3 * k.f3;
+                    row[j] = (float)v0;
+                    v3 = v2;
+                    v2 = v1;
+                    v1 = v0;
+                }
+                for (int jb = jfull - 16; jb >= 0; jb -= 16) {
+                    float xs[16];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f4*>(xs + 4 * qq) = *reinterpret_cast<const f4*>(row + jb + 4 * qq);
+#pragma unroll
+                    for (int u = 15; u >= 0; --u) {
+                        double v0 = (double)xs[u];
+                        v0 *= k.sum;
+                        v0 += v1 * k.f1;
+                        v0 += v2 * k.f2;
+                        v0 += v3 * k.f3;
+                        xs[u] = (float)v0;
+                        v3 = v2;
+                        v2 = v1;
+                        v1 = v0;
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f4*>(row + jb + 4 * qq) = *reinterpret_cast<const f4*>(xs + 4 * qq);
+                }
+            }
+            __syncthreads();
+            stamp(2);  // x sweep
+            // ---- causal y sweep, lane = column c0+lane -----------------------------------------------------------
+            float* colp = tile + lane;
+            u64* slot = wf.yg + ((size_t)p * wf.NC + C) * WF_GRAN * WAVE;
+            double u1, u2, u3;
+            unsigned rowbits = 0;
+            if (R == 0) {
+                u1 = u2 = u3 = (double)colp[0] / k.sumsq;  // CImg.h:34909
+                rowbits = __float_as_uint(colp[0]);     // the x-blurred row (mask plane: identical for every y)
+            } else if (!granules_consume(slot, lane, (wf.epoch << 12) | (unsigned)R, wf.abort, u1, u2, u3, rowbits)) {
+                dead = true;
+                break;
+            }
+            stamp(3);  // y state wait
+            const float rowv = __uint_as_float(rowbits);
+            const double iplus_y = const_rows ? (double)rowv : (double)colp[(nrows - 1) * TP];  // last band only (CImg.h:34906)
+            for (int j0 = 0; j0 < nrows; j0 += 16) {
+                if (j0 + 16 <= nrows) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        double v0 = const_rows ? (double)rowv : (double)colp[(j0 + u) * TP];
+                        v0 += u1 * k.f1;
+                        v0 += u2 * k.f2;
+                        v0 += u3 * k.f3;
+                        colp[(j0 + u) * TP] = (float)v0;
+                        u3 = u2;
+                        u2 = u1;
+                        u1 = v0;
+                    }
+                } else {
+                    for (int j = j0; j < nrows; ++j) {
+                        double v0 = const_rows ? (double)rowv : (double)colp[j * TP];
+                        v0 += u1 * k.f1;
+                        v0 += u2 * k.f2;
+                        v0 += u3 * k.f3;
+                        colp[j * TP] = (float)v0;
+                        u3 = u2;
+                        u2 = u1;
+                        u1 = v0;
+                    }
+                }
+            }
+            if (R < wf.NR - 1)
+                granules_publish(slot, lane, (wf.epoch << 12) | (unsigned)(R + 1), u1, u2, u3, pass_row ? rowbits : 0u);
+            else {  // last band: the state the anticausal y sweep starts from ([4][planes][pitch], as k_vv_y_fwd leaves it)
+                const size_t n = (size_t)wf.NP * pitch, i = (size_t)p * pitch + c0 + lane;
+                state_y[i] = u1;
+                state_y[n + i] = u2;
+                state_y[2 * n + i] = u3;
+                state_y[3 * n + i] = iplus_y;
+            }
+            __syncthreads();
+            stamp(4);  // y sweep + publish
+            tile_store_rows(base, pitch, c0, lane, tile, nrows);  // a partial last band must not touch the next plane's rows
+            __syncthreads();  // the tile buffer is refilled next
+            stamp(5);  // store
+        }
+    }
+    if (STAMP && lane == 0)
+        for (int i = 0; i < 8; ++i) wf.dbg[(size_t)blockIdx.x * 8 + i] = seg[i];
 }
 
 // ---- B3': Deriche order 0, CImg.h:34779-34797 (all float).  The causal pass needs a line of temporaries Y; the

@@ -30,7 +30,7 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample=4):
+def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample=4, fused_sweep_levels=0):
     """SURVEY.md 8(d) byte accounting for one pair: every distinct input array read once + every output array
     written once, pyramid planes f32.  Returns per-kernel bytes (this implementation's kernels, each with its own
     inputs/outputs counted once) and the canonical stage totals S1..S3 the headline fraction uses."""
@@ -41,11 +41,13 @@ def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample
     s2 = sum(7 * 4 * (3 * n[l] + n[l + 1]) for l in range(L - 1))
     s3 = sum(4 * (10 * n[l] + 9 * n[l + 1]) for l in range(L - 1)) + 4 * 10 * n[L - 1]
     line = sum(2 * 7 * 4 * n[l] for l in range(L - 1))  # one recursive pass: read 7 planes, write 7 planes
+    F = min(fused_sweep_levels, L - 1)  # levels whose anticausal-x and causal-y sweeps are one kernel (one R + one W)
+    fused = sum(2 * 7 * 4 * n[l] for l in range(F))
     per_kernel = {
         "compose": s1,
         "seam": 2 * 4 * level_w[0],  # two mid rows
         "mask": 4 * P,               # the step written once (when it is materialised at all)
-        "vv_x_fwd": line, "vv_x_bwd": line, "vv_y_fwd": line, "vv_y_bwd": line,
+        "vv_x_fwd": line, "vv_x_bwd": line - fused, "vv_y_fwd": line - fused, "vv_y_bwd": line, "vv_xbyf": fused,
         "decimate": sum(7 * 4 * (n[l] + n[l + 1]) for l in range(L - 1)),
         "collapse_top": 4 * 10 * n[L - 1],
         "collapse": sum(4 * (10 * n[l] + 9 * n[l + 1]) for l in range(1, L - 1)),

@@ -133,6 +133,10 @@ int stitch_plan_capacity(const stitch_plan *plan);
 void stitch_plan_destroy(stitch_plan *plan);
 size_t stitch_plan_workspace_bytes(const stitch_plan *plan);
 int stitch_plan_levels(const stitch_plan *plan, int *level_w, int *level_h);
+/* Number of finest pyramid levels whose anticausal-x and causal-y sweeps run fused (k_vv_xbyf).  Chosen at plan
+ * creation: levels at least 1024 x 1024, at most two -- or exactly STITCH_WAVEFRONT=<n> levels when that environment
+ * variable is set (0 = always separate sweeps).  Results are identical either way. */
+int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
 
 int stitch_dev_blend_u8(stitch_plan *plan, const uint8_t *d_a, const uint8_t *d_b, uint8_t *d_out, void *stream);
 int stitch_dev_blend_f32(stitch_plan *plan, const float *d_a, const float *d_b, float *d_out, void *stream);
@@ -174,7 +178,8 @@ enum {
     STITCH_K_COLLAPSE_TOP = 8, /* k_blend_top: blend of the coarsest level                                       */
     STITCH_K_COLLAPSE = 9,     /* k_collapse<float,false>: expand + Laplacian + blend + collapse, levels 1..L-2  */
     STITCH_K_COLLAPSE_L0 = 10, /* k_collapse<T,true>: the same at level 0, writing the dense output canvas       */
-    STITCH_K_COUNT = 11
+    STITCH_K_VV_XBYF = 11,     /* k_vv_xbyf: anticausal-x + causal-y sweeps fused (row-band pipeline), finest levels */
+    STITCH_K_COUNT = 12
 };
 int stitch_plan_set_profiling(stitch_plan *plan, int enabled);
 /* Record events only around launches of one kernel id (near-zero overhead inside a timed region). */

@@ -15,15 +15,16 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 steps_total = None  # derived below: k_compose runs once per step
 
 GROUP = {"k_compose": "compose", "k_seam": "seam", "k_mask": "mask", "k_vv_x_fwd": "vv_x_fwd",
          "k_vv_x_bwd": "vv_x_bwd", "k_vv_y_fwd": "vv_y_fwd", "k_vv_y_bwd_dec": "vv_y_bwd", "k_vv_y_bwd": "vv_y_bwd",
          "k_decimate": "decimate", "k_collapse<float, false>": "collapse", "k_collapse<float, true>": "collapse_l0",
-         "k_collapse<unsigned char, true>": "collapse_l0", "k_blend_top": "collapse_top"}
-LAUNCH_GROUPS = {"compose": 1, "seam": 1, "mask": 1, "vv_x_fwd": 11, "vv_x_bwd": 11, "vv_y_fwd": 11, "vv_y_bwd": 11, "decimate": 0,
-                 "collapse_top": 1, "collapse": 10, "collapse_l0": 1}
+         "k_collapse<unsigned char, true>": "collapse_l0", "k_blend_top": "collapse_top", "k_vv_xbyf<false>": "vv_xbyf",
+         "k_vv_xbyf<true>": "vv_xbyf"}
+LAUNCH_GROUPS = {"compose": 1, "seam": 1, "mask": 1, "vv_x_fwd": 11, "vv_x_bwd": 9, "vv_y_fwd": 9, "vv_y_bwd": 11, "decimate": 0,
+                 "collapse_top": 1, "collapse": 10, "collapse_l0": 1, "vv_xbyf": 2}  # config 2 with two fused-sweep levels
 
 
 def kname(full):
@@ -31,7 +32,7 @@ def kname(full):
     s = s[s.index("sk::") + 4:] if "sk::" in s else s
     if "(" in s:
         s = s[: s.index("(")]
-    if s.startswith("k_collapse<"):
+    if s.startswith("k_collapse<") or s.startswith("k_vv_xbyf<"):
         return s
     return s[: s.index("<")] if "<" in s else s
 
