@@ -243,3 +243,46 @@ def test_config5_size_single_gpu_against_oracle(st, gpu, oracle):
     err = float(np.abs(got - ref).max())
     assert err <= TOL_F32, err
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"within tolerance ({err}) but not bit-equal"
+
+
+def test_fused_sweep_under_concurrent_load(st, gpu, oracle):
+    """The band-pipeline sweep (inter-workgroup granule hand-offs) while the chip is busy: three batched plans of
+    three pairs each in flight on three HIP streams, repeated with fresh epochs, at a size where the fused sweep is
+    chosen automatically (levels >= 1024 x 1024) and the last band / column block are partial.  Every output of every
+    repetition must equal the oracle's."""
+    import torch
+    from computervisionimagestich2_amd import capi
+    fw, fh, cw, ch = 1500, 1100, 2200, 1100
+    S, B, REPS = 3, 3, 4
+    plans = [capi.Plan(cw, ch, max_pairs=B) for _ in range(S)]
+    assert plans[0].fused_sweep_levels >= 1
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    items, refs = [], []
+    for s_ in range(S):
+        lane = []
+        for q in range(B):
+            i = s_ * B + q
+            A, Bf = oracle.synth(fw, fh, 2 * i, np.float32), oracle.synth(fw, fh, 2 * i + 1, np.float32)
+            P = [1.0, 0.002, 1e-6, -700.0 - 8.0 * i, -0.001, 1.0, 5e-7, 1.5]
+            rc, ref = oracle.pair(Bf, P, 0.0, 0.0, A, 0, 0, cw, ch)
+            assert rc == 0
+            refs.append(ref)
+            lane.append((torch.from_numpy(Bf).to(gpu), P, 0.0, 0.0, torch.from_numpy(A).to(gpu), 0, 0,
+                         torch.empty((3, ch, cw), dtype=torch.float32, device=gpu)))
+        items.append(lane)
+    torch.cuda.synchronize()
+    for rep in range(REPS):
+        for lane in items:
+            for it in lane:
+                it[7].fill_(-1.0)
+        for s_ in range(S):
+            with torch.cuda.stream(streams[s_]):
+                plans[s_].pairs(items[s_])
+        torch.cuda.synchronize()
+        for s_ in range(S):
+            for q in range(B):
+                plans[s_].status(q)
+                got = items[s_][q][7].cpu().numpy()
+                assert np.array_equal(got.view(np.uint32), refs[s_ * B + q].view(np.uint32)), (rep, s_, q)
+    for p in plans:
+        p.close()
