@@ -16,6 +16,7 @@
 //   ImageProcess::movingImageByOffset(src, dst&, int, int)                   ImageProcess.cpp:608-620  -> stitch_move_u8
 //   ImageProcess::blendTwoImages(a, b)                                       ImageProcess.cpp:648-773  -> stitch_blend_u8
 //   equalization::equalization(CImg<uchar>&, int)                            equalization.cpp:4-25     -> stitch_equalize_u8
+//   ImageProcess::toGrayScale(const CImg<uchar>&)                            ImageProcess.cpp:27-40    -> stitch_gray_u8
 //
 // How the definitions take effect is described in INTEGRATION.md: link-time replacement for Projection.o and
 // equalization.o; for the three ImageProcess members (same translation unit as the control flow) either the
@@ -34,7 +35,7 @@
 #include "stitch.h"
 
 namespace {
-int g_calls[5] = {0, 0, 0, 0, 0};  // project, warp, move, blend, equalize -- lets a harness prove which code ran
+int g_calls[6] = {0, 0, 0, 0, 0, 0};  // project, warp, move, blend, equalize, gray -- lets a harness prove which code ran
 void check(int rc, const char* what) {
     if (rc == STITCH_OK) return;
     // The reference signals no errors on this path (degenerate inputs hang or crash it); the drop-in
@@ -43,8 +44,8 @@ void check(int rc, const char* what) {
 }
 }  // namespace
 
-// number of times each replaced function has run in this process (0 project, 1 warp, 2 move, 3 blend, 4 equalize)
-extern "C" int stitch_dropin_call_count(int which) { return which >= 0 && which < 5 ? g_calls[which] : -1; }
+// number of times each replaced function has run in this process (0 project, 1 warp, 2 move, 3 blend, 4 equalize, 5 gray)
+extern "C" int stitch_dropin_call_count(int which) { return which >= 0 && which < 6 ? g_calls[which] : -1; }
 
 CImg<unsigned char> Projection::imageProjection(const CImg<unsigned char>& src) {
     if (src.spectrum() != CHANNEL_NUM || src.depth() != 1) throw std::runtime_error("imageProjection: expected a 3-channel 2-D image");
@@ -60,6 +61,15 @@ unsigned char Projection::bilinearInterpolation(const CImg<unsigned char>&, floa
     // given a host implementation: the drop-in has no CPU path.
     std::fprintf(stderr, "stitch drop-in: Projection::bilinearInterpolation is not reachable in this build\n");
     std::abort();
+}
+
+// ImageProcess.cpp:27-40 -- the step right after the projection on the same buffer
+CImg<unsigned char> ImageProcess::toGrayScale(const CImg<unsigned char>& src) {
+    if (src.spectrum() == 1) return src;  // :29-31
+    ++g_calls[5];
+    CImg<unsigned char> gray(src.width(), src.height(), src.depth(), 1);
+    check(stitch_gray_u8(src.data(), src.width(), src.height(), gray.data(), nullptr), "stitch_gray_u8");
+    return gray;
 }
 
 void ImageProcess::warpingImageByHomography(const CImg<unsigned char>& src, CImg<unsigned char>& dst, Homography& H,

@@ -212,6 +212,48 @@ def finish(result, num=19.0, den=20.0):
     return result, hist
 
 
+def gray(rgb):
+    """ImageProcess::toGrayScale + SIFT float staging (ImageProcess.cpp:27-40,47-51) -> (gray uint8 (H,W), float32 (H,W))."""
+    rgb = np.ascontiguousarray(_img(rgb), np.uint8)
+    _, h, w = rgb.shape
+    g, f = np.empty((h, w), np.uint8), np.empty((h, w), np.float32)
+    _chk(lib().stitch_gray_u8(_p(rgb), w, h, _p(g), _p(f)))
+    return g, f
+
+
+def project_gray(src, fov_deg=15.0):
+    """readFile's per-image chain in one kernel (ImageProcess.cpp:18-20) -> (projected, gray, gray_f32)."""
+    src = np.ascontiguousarray(_img(src), np.uint8)
+    _, h, w = src.shape
+    dst, g, f = np.empty_like(src), np.empty((h, w), np.uint8), np.empty((h, w), np.float32)
+    _chk(lib().stitch_project_gray_u8(_p(src), w, h, C.c_float(fov_deg), _p(dst), _p(g), _p(f)))
+    return dst, g, f
+
+
+def canvas_bbox(fw, fh, p_fwd, result_w, result_h):
+    """Canvas of one stitch step (ImageProcess.cpp:206-216) -> (min_x, min_y, new_w, new_h).  Host arithmetic."""
+    mx, my, nw, nh = C.c_float(), C.c_float(), C.c_int(), C.c_int()
+    _chk(lib().stitch_canvas_bbox(int(fw), int(fh), _map8(p_fwd), int(result_w), int(result_h), C.byref(mx), C.byref(my),
+                                  C.byref(nw), C.byref(nh)))
+    return mx.value, my.value, nw.value, nh.value
+
+
+def map_points(x, y, p_fwd, offx, offy):
+    """updateFeaturesByHomography (ImageProcess.cpp:622-631) -> (x, y, ix, iy)."""
+    x, y = np.array(x, np.float32), np.array(y, np.float32)
+    ix, iy = np.empty(x.size, np.int32), np.empty(x.size, np.int32)
+    _chk(lib().stitch_map_points(_p(x), _p(y), _p(ix), _p(iy), x.size, _map8(p_fwd), C.c_float(offx), C.c_float(offy)))
+    return x, y, ix, iy
+
+
+def shift_points(x, y, ox, oy):
+    """updateFeaturesByOffset (ImageProcess.cpp:633-640) -> (x, y, ix, iy)."""
+    x, y = np.array(x, np.float32), np.array(y, np.float32)
+    ix, iy = np.empty(x.size, np.int32), np.empty(x.size, np.int32)
+    _chk(lib().stitch_shift_points(_p(x), _p(y), _p(ix), _p(iy), x.size, int(ox), int(oy)))
+    return x, y, ix, iy
+
+
 # ---- device-resident entry points (torch tensors on the HIP device) --------------------------------------------
 def _tsfx(t):
     import torch

@@ -498,12 +498,14 @@ void seam_to_public(const SeamDev& d, stitch_seam* o) {
 }
 
 template <typename PX>
-int dev_project(const PX* d_src, int w, int h, float fov_deg, PX* d_dst, void* stream) {
+int dev_project(const PX* d_src, int w, int h, float fov_deg, PX* d_dst, void* stream, uint8_t* d_gray = nullptr,
+                float* d_gray_f32 = nullptr) {
     int rc = need_device();
     if (rc) return rc;
     if (!d_src || !d_dst || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "project: null buffer or bad size %dx%d", w, h);
     const ProjParams pp = proj_params(w, h, fov_deg);
-    k_project<PX><<<grid_xy(w, h), 256, 0, as_stream(stream)>>>(d_src, d_dst, w, h, pp.flag, pp.width, pp.height, pp.r);
+    k_project<PX><<<grid_xy(w, h), 256, 0, as_stream(stream)>>>(d_src, d_dst, w, h, pp.flag, pp.width, pp.height, pp.r, d_gray,
+                                                                d_gray_f32);
     return launch_check("k_project");
 }
 
@@ -857,7 +859,8 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     int wf_levels = 0;
     if (const char* e = std::getenv("STITCH_WAVEFRONT"))
         wf_levels = std::max(0, std::min(4, std::atoi(e)));
-    else  // auto: the band pipeline pays where a level has many bands and tiles to stream (fill = bands x hand-off)
+    else if (max_pairs >= 2)  // auto: the band pipeline pays where a level has many bands and tiles to stream and other
+                              // pairs' work hides its fill (bands x hand-off latency); a lone pair is faster unfused
         while (wf_levels < 2 && wf_levels < L - 1 && lw[wf_levels] >= 1024 && lh[wf_levels] >= 1024) ++wf_levels;
     if (o.blur_kind != 0 || std::getenv("STITCH_NO_FUSE") || o.sigma < 0.5f) wf_levels = 0;
     wf_levels = std::min(wf_levels, L - 1);
@@ -1074,6 +1077,98 @@ int stitch_dev_lummix_u8(uint8_t* d_result, const uint8_t* d_equalized, int w, i
 
 int stitch_dev_finish_u8(uint8_t* d_result, int w, int h, double num, double den, int32_t* d_hist256, void* stream) {
     return dev_equalize_impl(d_result, w, h, d_hist256, true, num, den, stream);
+}
+
+// ---- SURVEY.md 8(f) rows 1 and 2 -------------------------------------------------------------------------------
+int stitch_dev_gray_u8(const uint8_t* d_rgb, int w, int h, uint8_t* d_gray, float* d_gray_f32, void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_rgb || (!d_gray && !d_gray_f32) || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "gray: bad argument");
+    const size_t n = (size_t)w * h;
+    k_gray<<<eq_grid(n), 256, 0, as_stream(stream)>>>(d_rgb, n, d_gray, d_gray_f32);
+    return launch_check("k_gray");
+}
+int stitch_dev_project_gray_u8(const uint8_t* d_src, int w, int h, float fov_deg, uint8_t* d_projected, uint8_t* d_gray,
+                               float* d_gray_f32, void* stream) {
+    return dev_project<uint8_t>(d_src, w, h, fov_deg, d_projected, stream, d_gray, d_gray_f32);
+}
+int stitch_gray_u8(const uint8_t* rgb, int w, int h, uint8_t* gray, float* gray_f32) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!rgb || (!gray && !gray_f32) || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "gray: bad argument");
+    const size_t n = (size_t)w * h;
+    DevBuf d, g, f;
+    if ((rc = d.alloc(n * 3)) || (rc = g.alloc(n)) || (rc = f.alloc(n * sizeof(float)))) return rc;
+    HIPCHK(hipMemcpy(d.p, rgb, n * 3, hipMemcpyHostToDevice));
+    if ((rc = stitch_dev_gray_u8(d.as<uint8_t>(), w, h, g.as<uint8_t>(), f.as<float>(), nullptr))) return rc;
+    if (gray) HIPCHK(hipMemcpy(gray, g.p, n, hipMemcpyDeviceToHost));
+    if (gray_f32) HIPCHK(hipMemcpy(gray_f32, f.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+int stitch_project_gray_u8(const uint8_t* src, int w, int h, float fov_deg, uint8_t* projected, uint8_t* gray, float* gray_f32) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!src || !projected || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "project_gray: bad argument");
+    const size_t n = (size_t)w * h;
+    DevBuf s, d, g, f;
+    if ((rc = s.alloc(n * 3)) || (rc = d.alloc(n * 3)) || (rc = g.alloc(n)) || (rc = f.alloc(n * sizeof(float)))) return rc;
+    HIPCHK(hipMemcpy(s.p, src, n * 3, hipMemcpyHostToDevice));
+    if ((rc = stitch_dev_project_gray_u8(s.as<uint8_t>(), w, h, fov_deg, d.as<uint8_t>(), g.as<uint8_t>(), f.as<float>(), nullptr)))
+        return rc;
+    HIPCHK(hipMemcpy(projected, d.p, n * 3, hipMemcpyDeviceToHost));
+    if (gray) HIPCHK(hipMemcpy(gray, g.p, n, hipMemcpyDeviceToHost));
+    if (gray_f32) HIPCHK(hipMemcpy(gray_f32, f.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+
+// Canvas sizing of one stitch step, ImageProcess.cpp:206-216 with getMin/MaxX/YAfterWarping (:532-594): float
+// arithmetic exactly as written there (the map itself in double, rounded to float per corner).  Host only.
+static float map_x(const double p[8], float x, float y) { return (float)(p[0] * (double)x + p[1] * (double)y + p[2] * (double)x * (double)y + p[3]); }
+static float map_y(const double p[8], float x, float y) { return (float)(p[4] * (double)x + p[5] * (double)y + p[6] * (double)x * (double)y + p[7]); }
+int stitch_canvas_bbox(int fw, int fh, const double p_fwd[8], int result_w, int result_h, float* min_x, float* min_y, int* new_w,
+                       int* new_h) {
+    if (!p_fwd || !min_x || !min_y || !new_w || !new_h || fw <= 0 || fh <= 0 || result_w <= 0 || result_h <= 0)
+        return fail(STITCH_ERR_ARG, "canvas_bbox: bad argument");
+    const float cx[4] = {0.f, (float)(fw - 1), 0.f, (float)(fw - 1)}, cy[4] = {0.f, 0.f, (float)(fh - 1), (float)(fh - 1)};
+    float mnx = map_x(p_fwd, cx[0], cy[0]), mxx = mnx, mny = map_y(p_fwd, cx[0], cy[0]), mxy = mny;
+    for (int i = 1; i < 4; ++i) {  // strict comparisons in the reference's corner order (0,0) (w-1,0) (0,h-1) (w-1,h-1)
+        const float X = map_x(p_fwd, cx[i], cy[i]), Y = map_y(p_fwd, cx[i], cy[i]);
+        if (X < mnx) mnx = X;
+        if (X > mxx) mxx = X;
+        if (Y < mny) mny = Y;
+        if (Y > mxy) mxy = Y;
+    }
+    mnx = (mnx < 0) ? mnx : 0;                                  // :207
+    mny = (mny < 0) ? mny : 0;                                  // :209
+    mxx = (mxx >= (float)result_w) ? mxx : (float)result_w;    // :211
+    mxy = (mxy >= (float)result_h) ? mxy : (float)result_h;    // :213
+    *min_x = mnx;
+    *min_y = mny;
+    *new_w = (int)std::ceil(mxx - mnx);  // :215 (float subtraction)
+    *new_h = (int)std::ceil(mxy - mny);
+    return STITCH_OK;
+}
+// updateFeaturesByHomography / updateFeaturesByOffset, ImageProcess.cpp:622-640, on arrays of keypoint coordinates
+int stitch_map_points(float* x, float* y, int32_t* ix, int32_t* iy, int n, const double p_fwd[8], float offx, float offy) {
+    if (!x || !y || !p_fwd || n < 0) return fail(STITCH_ERR_ARG, "map_points: bad argument");
+    for (int i = 0; i < n; ++i) {
+        const float cx = x[i], cy = y[i];
+        x[i] = map_x(p_fwd, cx, cy) - offx;
+        y[i] = map_y(p_fwd, cx, cy) - offy;
+        if (ix) ix[i] = (int32_t)x[i];
+        if (iy) iy[i] = (int32_t)y[i];
+    }
+    return STITCH_OK;
+}
+int stitch_shift_points(float* x, float* y, int32_t* ix, int32_t* iy, int n, int ox, int oy) {
+    if (!x || !y || n < 0) return fail(STITCH_ERR_ARG, "shift_points: bad argument");
+    for (int i = 0; i < n; ++i) {
+        x[i] -= (float)ox;
+        y[i] -= (float)oy;
+        if (ix) ix[i] = (int32_t)x[i];
+        if (iy) iy[i] = (int32_t)y[i];
+    }
+    return STITCH_OK;
 }
 
 int stitch_dev_synth_u8(uint8_t* d_dst, int w, int h, int frame_id, void* stream) {

@@ -75,12 +75,29 @@ __device__ __forceinline__ void bilinear3(const PX* __restrict__ src, int w, int
     }
 }
 
+// ---- gray conversion + SIFT input staging ---------------------------------------------
+// ImageProcess::toGrayScale, ImageProcess.cpp:27-40: gray = 0.299*R + 0.587*G + 0.114*B evaluated in double on
+// float-cast pixels, stored to unsigned char by truncation; siftAlgorithm stages it as float (:47-51).
+__device__ __forceinline__ uint8_t gray_ref(uint8_t r, uint8_t g, uint8_t b) {
+    return (uint8_t)(int)(0.299 * (double)(float)r + 0.587 * (double)(float)g + 0.114 * (double)(float)b);
+}
+__global__ __launch_bounds__(256) void k_gray(const uint8_t* __restrict__ rgb, size_t n, uint8_t* __restrict__ gray,
+                                              float* __restrict__ gray_f32) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint8_t v = gray_ref(rgb[i], rgb[i + n], rgb[i + 2 * n]);
+        if (gray) gray[i] = v;
+        if (gray_f32) gray_f32[i] = (float)v;
+    }
+}
+
 // ---- P1: cylindrical projection, Projection.cpp:20-73 ------------------------------------------------------
 // One output pixel (three channels) per work-item; r is computed on the host (tan).  Writes 0 where the
 // source coordinate falls outside, so no memset pass is needed.
 template <typename PX>
 __global__ __launch_bounds__(256) void k_project(const PX* __restrict__ src, PX* __restrict__ dst, int w, int h,
-                                                 int flag, int width, int height, float r) {
+                                                 int flag, int width, int height, float r, uint8_t* __restrict__ gray,
+                                                 float* __restrict__ gray_f32) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= w) return;
@@ -102,6 +119,11 @@ __global__ __launch_bounds__(256) void k_project(const PX* __restrict__ src, PX*
     dst[off] = o[0];
     dst[off + pl] = o[1];
     dst[off + 2 * pl] = o[2];
+    if (sizeof(PX) == 1 && (gray || gray_f32)) {  // readFile's next step on the same pixel (ImageProcess.cpp:20)
+        const uint8_t v = gray_ref((uint8_t)o[0], (uint8_t)o[1], (uint8_t)o[2]);
+        if (gray) gray[off] = v;
+        if (gray_f32) gray_f32[off] = (float)v;
+    }
 }
 
 // ---- W1: the bilinear map, ImageProcess.cpp:465-471 --------------------------------------------------------
@@ -857,11 +879,17 @@ __device__ __forceinline__ void granules_publish(u64* base, int lane, unsigned t
 // Wave-uniform exit; false on timeout / abort.
 __device__ __forceinline__ bool granules_consume(const u64* base, int lane, unsigned tag, unsigned* abort, double& a, double& b,
                                                  double& c, unsigned& extra) {
+#ifndef STITCH_WF_POLL
+#define STITCH_WF_POLL 0
+#endif
     for (unsigned spins = 0;; ++spins) {
-        unsigned seen = 0;
-        if (lane == 0)
-            seen = (unsigned)(__hip_atomic_load((gu64*)(base + 5 * WAVE + (WAVE - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
-        seen = __shfl(seen, 0, 64);
+        unsigned seen = tag;
+        if (STITCH_WF_POLL < 2) {
+            seen = 0;
+            if (lane == 0)
+                seen = (unsigned)(__hip_atomic_load((gu64*)(base + 5 * WAVE + (WAVE - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+            seen = __shfl(seen, 0, 64);
+        }
         if (seen == tag) {
             u64 g[WF_GRAN];
             bool ok = true;
@@ -877,7 +905,8 @@ __device__ __forceinline__ bool granules_consume(const u64* base, int lane, unsi
                 c = __longlong_as_double((long long)((g[4] & 0xffffffffu) | (g[5] << 32)));
                 return true;
             }
-        } else {
+        }
+        {
             if ((spins & 31) == 31) {
                 unsigned ab = 0;
                 if (lane == 0) ab = __hip_atomic_load((gu32*)abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -887,7 +916,8 @@ __device__ __forceinline__ bool granules_consume(const u64* base, int lane, unsi
                     return false;
                 }
             }
-            __builtin_amdgcn_s_sleep(32);
+            if (STITCH_WF_POLL == 0) __builtin_amdgcn_s_sleep(32);
+            if (STITCH_WF_POLL == 2) __builtin_amdgcn_s_sleep(4);
         }
     }
 }

@@ -134,8 +134,9 @@ void stitch_plan_destroy(stitch_plan *plan);
 size_t stitch_plan_workspace_bytes(const stitch_plan *plan);
 int stitch_plan_levels(const stitch_plan *plan, int *level_w, int *level_h);
 /* Number of finest pyramid levels whose anticausal-x and causal-y sweeps run fused (k_vv_xbyf).  Chosen at plan
- * creation: levels at least 1024 x 1024, at most two -- or exactly STITCH_WAVEFRONT=<n> levels when that environment
- * variable is set (0 = always separate sweeps).  Results are identical either way. */
+ * creation: for batched plans (max_pairs >= 2) the levels of at least 1024 x 1024, at most two -- or exactly
+ * STITCH_WAVEFRONT=<n> levels when that environment variable is set (0 = always separate sweeps).  Results are
+ * identical either way. */
 int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
 
 int stitch_dev_blend_u8(stitch_plan *plan, const uint8_t *d_a, const uint8_t *d_b, uint8_t *d_out, void *stream);
@@ -193,6 +194,26 @@ int stitch_dev_equalize_u8(uint8_t *d_img, int w, int h, int32_t *d_hist256, voi
 int stitch_dev_lummix_u8(uint8_t *d_result, const uint8_t *d_equalized, int w, int h, double num, double den,
                          void *stream);
 int stitch_dev_finish_u8(uint8_t *d_result, int w, int h, double num, double den, int32_t *d_hist256, void *stream);
+
+/* ---- the callers either side of the path ----------------------------------------------------- */
+/* ImageProcess::toGrayScale (ImageProcess.cpp:27-40) and the float staging of siftAlgorithm (:47-51):
+ * gray = (uchar)(0.299 R + 0.587 G + 0.114 B) in double; gray_f32 = (float)gray = VLFeat's vl_sift_pix input.
+ * Either output may be NULL. */
+int stitch_gray_u8(const uint8_t *rgb, int w, int h, uint8_t *gray, float *gray_f32);
+int stitch_dev_gray_u8(const uint8_t *d_rgb, int w, int h, uint8_t *d_gray, float *d_gray_f32, void *stream);
+/* readFile's per-image chain in one kernel (ImageProcess.cpp:18-20): projection + gray + float staging. */
+int stitch_project_gray_u8(const uint8_t *src, int w, int h, float fov_deg, uint8_t *projected, uint8_t *gray,
+                           float *gray_f32);
+int stitch_dev_project_gray_u8(const uint8_t *d_src, int w, int h, float fov_deg, uint8_t *d_projected, uint8_t *d_gray,
+                               float *d_gray_f32, void *stream);
+/* Canvas of one stitch step from the FORWARD map (ImageProcess.cpp:206-216 with :532-594): min_x/min_y (<= 0) are
+ * the offsets handed to warp (as floats) and move (truncated); new_w x new_h is the canvas.  Host arithmetic. */
+int stitch_canvas_bbox(int fw, int fh, const double p_fwd[8], int result_w, int result_h, float *min_x, float *min_y,
+                       int *new_w, int *new_h);
+/* updateFeaturesByHomography / updateFeaturesByOffset (ImageProcess.cpp:622-640) on keypoint coordinate arrays
+ * (ix/iy = the truncated integer coordinates, optional).  Host arithmetic. */
+int stitch_map_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, const double p_fwd[8], float offx, float offy);
+int stitch_shift_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, int ox, int oy);
 
 /* Deterministic synthetic frames of the benchmark configs: values 1..250, never 0 ("empty" to
  * the seam scan); the float twin adds a 16-bit fraction.  Same generator as oracle_synth_* (tests compare). */

@@ -88,6 +88,59 @@ REF_API void ref_bbox(int w, int h, const double p[8], float out[4]) {
     out[3] = fake_ip()->getMaxYAfterWarping(s, H);
 }
 
+REF_API int ref_gray_u8(const uint8_t *rgb, int w, int h, uint8_t *gray) {
+    // ImageProcess::toGrayScale, ImageProcess.cpp:27-40
+    U8Img s(rgb, w, h, 1, 3, true);
+    U8Img g = fake_ip()->toGrayScale(s);
+    if (g.width() != w || g.height() != h || g.spectrum() != 1) return -1;
+    std::memcpy(gray, g.data(), (size_t)w * h);
+    return 0;
+}
+
+REF_API void ref_update_features(float *x, float *y, int *ix, int *iy, int n, const double p[8], float offx, float offy, int ox,
+                                 int oy, int by_offset) {
+    // updateFeaturesByHomography / updateFeaturesByOffset, ImageProcess.cpp:622-640, on a feature map built here
+    std::map<std::vector<float>, VlSiftKeypoint> feat;
+    for (int i = 0; i < n; ++i) {
+        VlSiftKeypoint k;
+        std::memset(&k, 0, sizeof k);
+        k.x = x[i];
+        k.y = y[i];
+        feat[std::vector<float>(1, (float)i)] = k;  // keys keep the insertion order 0..n-1
+    }
+    Homography H = make_h(p);
+    if (by_offset)
+        fake_ip()->updateFeaturesByOffset(feat, ox, oy);
+    else
+        fake_ip()->updateFeaturesByHomography(feat, H, offx, offy);
+    int i = 0;
+    for (auto it = feat.begin(); it != feat.end(); ++it, ++i) {
+        x[i] = it->second.x;
+        y[i] = it->second.y;
+        ix[i] = it->second.ix;
+        iy[i] = it->second.iy;
+    }
+}
+
+REF_API void ref_canvas(int fw, int fh, const double p[8], int result_w, int result_h, float *min_x, float *min_y, int *new_w,
+                        int *new_h) {
+    // the canvas sizing statements of matching(), ImageProcess.cpp:206-216, on the reference's own corner functions
+    Homography H = make_h(p);
+    U8Img s(fw, fh, 1, 3, 0);
+    float mnx = fake_ip()->getMinXAfterWarping(s, H);
+    mnx = (mnx < 0) ? mnx : 0;
+    float mny = fake_ip()->getMinYAfterWarping(s, H);
+    mny = (mny < 0) ? mny : 0;
+    float mxx = fake_ip()->getMaxXAfterWarping(s, H);
+    mxx = (mxx >= result_w) ? mxx : result_w;
+    float mxy = fake_ip()->getMaxYAfterWarping(s, H);
+    mxy = (mxy >= result_h) ? mxy : result_h;
+    *min_x = mnx;
+    *min_y = mny;
+    *new_w = ceil(mxx - mnx);
+    *new_h = ceil(mxy - mny);
+}
+
 REF_API int ref_warp_u8(const uint8_t *src, int sw, int sh, const double p[8], float offx, float offy,
                         uint8_t *canvas, int cw, int ch) {
     U8Img s(src, sw, sh, 1, 3, true);

@@ -700,6 +700,66 @@ int oracle_lummix_u8(uint8_t *result, const uint8_t *equalized, int w, int h, do
     return ORACLE_OK;
 }
 
+/* ImageProcess::toGrayScale, ImageProcess.cpp:27-40 (double expression on float-cast pixels, truncated into an
+ * unsigned char image) and siftAlgorithm's float staging, :47-51 */
+int oracle_gray_u8(const uint8_t *rgb, int w, int h, uint8_t *gray, float *gray_f32) {
+    if (!rgb || w <= 0 || h <= 0) return ORACLE_ERR_ARG;
+    const size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t v = (uint8_t)(0.299 * (float)rgb[i] + 0.587 * (float)rgb[i + n] + 0.114 * (float)rgb[i + 2 * n]);
+        if (gray) gray[i] = v;
+        if (gray_f32) gray_f32[i] = (float)v;
+    }
+    return ORACLE_OK;
+}
+
+/* ImageProcess.cpp:206-216 with getMin/MaxX/YAfterWarping (:532-594): corners visited in the order
+ * (0,0) (w-1,0) (0,h-1) (w-1,h-1) with strict comparisons; clamps and the ceil of a FLOAT difference as written. */
+int oracle_canvas_bbox(int fw, int fh, const double p[8], int result_w, int result_h, float *min_x, float *min_y, int *new_w,
+                       int *new_h) {
+    if (!p || fw <= 0 || fh <= 0) return ORACLE_ERR_ARG;
+    const float cx[4] = {0.f, (float)(fw - 1), 0.f, (float)(fw - 1)}, cy[4] = {0.f, 0.f, (float)(fh - 1), (float)(fh - 1)};
+    float X, Y;
+    oracle_map_xy(cx[0], cy[0], p, &X, &Y);
+    float mnx = X, mxx = X, mny = Y, mxy = Y;
+    for (int i = 1; i < 4; ++i) {
+        oracle_map_xy(cx[i], cy[i], p, &X, &Y);
+        if (X < mnx) mnx = X;
+        if (X > mxx) mxx = X;
+        if (Y < mny) mny = Y;
+        if (Y > mxy) mxy = Y;
+    }
+    mnx = (mnx < 0) ? mnx : 0;
+    mny = (mny < 0) ? mny : 0;
+    mxx = (mxx >= result_w) ? mxx : result_w;
+    mxy = (mxy >= result_h) ? mxy : result_h;
+    *min_x = mnx;
+    *min_y = mny;
+    *new_w = (int)ceilf(mxx - mnx);
+    *new_h = (int)ceilf(mxy - mny);
+    return ORACLE_OK;
+}
+
+/* updateFeaturesByHomography, ImageProcess.cpp:622-631; updateFeaturesByOffset, :633-640 */
+void oracle_map_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, const double p[8], float offx, float offy) {
+    for (int i = 0; i < n; ++i) {
+        float X, Y;
+        oracle_map_xy(x[i], y[i], p, &X, &Y);
+        x[i] = X - offx;
+        y[i] = Y - offy;
+        if (ix) ix[i] = (int32_t)x[i];
+        if (iy) iy[i] = (int32_t)y[i];
+    }
+}
+void oracle_shift_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, int ox, int oy) {
+    for (int i = 0; i < n; ++i) {
+        x[i] -= ox;
+        y[i] -= oy;
+        if (ix) ix[i] = (int32_t)x[i];
+        if (iy) iy[i] = (int32_t)y[i];
+    }
+}
+
 /* Synthetic frames, SURVEY.md 8(d): v = 1 + ((3x+5y+37c+101f) mod 200) + (splitmix64(seed ^ key) mod 50),
  * never 0.  The float twin adds frac = ((hash>>32)&0xFFFF)/65536. */
 static inline uint64_t splitmix64(uint64_t x) {

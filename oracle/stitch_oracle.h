@@ -88,6 +88,13 @@ int oracle_pair_f32(const float *frame, int fw, int fh, const double p[8], float
 int oracle_equalize_u8(uint8_t *img, int w, int h, int32_t hist[256], int32_t lut[256]);
 /* M1     ImageProcess.cpp:240-268: Y = Y*num/den + Yeq/den (root 19,20; src/ex6 5,6); in place on result */
 int oracle_lummix_u8(uint8_t *result, const uint8_t *equalized, int w, int h, double num, double den);
+/* ImageProcess::toGrayScale (ImageProcess.cpp:27-40) + float staging (:47-51);
+ * canvas sizing (ImageProcess.cpp:206-216, :532-594); feature updates (:622-640) */
+int oracle_gray_u8(const uint8_t *rgb, int w, int h, uint8_t *gray, float *gray_f32);
+int oracle_canvas_bbox(int fw, int fh, const double p_fwd[8], int result_w, int result_h, float *min_x, float *min_y,
+                       int *new_w, int *new_h);
+void oracle_map_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, const double p_fwd[8], float offx, float offy);
+void oracle_shift_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, int ox, int oy);
 /* synthetic frame generator of SURVEY.md 8(d) */
 void oracle_synth_u8(uint8_t *dst, int w, int h, int frame_id);
 void oracle_synth_f32(float *dst, int w, int h, int frame_id);

@@ -66,6 +66,15 @@ def main():
         J["project_synth"].append({"w": w, "h": h, "frame_id": f, "src_sha256": sha(src), "out_sha256": sha(out)})
         if w * h <= 40000:
             Z[f"project_synth_{w}x{h}"] = out
+    # toGrayScale of the projected frames, the image SIFT consumes
+    J["gray_input"] = [{"sha256": sha(R.gray(p)), "sum": int(R.gray(p).sum())} for p in proj]
+    # canvas sizing + feature updates of the recorded 4-frame run are pinned through the runs' cw/ch below; explicit
+    # vectors for the sizing function:
+    J["canvas"] = []
+    for (fw, fh, rw, rh, pp) in [(384, 512, 384, 512, [0.9724, -0.0398, 0.000149, 206.67, 0.00141, 1.00076, -1.2e-06, 4.55]),
+                                 (384, 512, 607, 517, [1.08, 0.03, -0.0003, -232.1, -0.0045, 0.997, 7.3e-06, -3.9]),
+                                 (600, 800, 1500, 820, [1.01, 0.2, 1e-5, 700.5, 0.1, 0.98, 2e-5, -30.25])]:
+        J["canvas"].append({"fw": fw, "fh": fh, "rw": rw, "rh": rh, "p": pp, "out": list(R.canvas(fw, fh, pp, rw, rh))})
     # scalar bilinear taps
     src = O.synth(31, 17, 9)
     pts = [(0.0, 0.0), (29.5, 15.25), (30.0, 16.0), (12.75, 3.5), (29.999, 15.999), (0.25, 15.75)]

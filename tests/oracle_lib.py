@@ -194,6 +194,30 @@ class Oracle:
         assert rc == 0, rc
         return result
 
+    def gray(self, rgb):
+        rgb = _img(rgb, np.uint8)
+        _, h, w = rgb.shape
+        g, f = np.empty((h, w), np.uint8), np.empty((h, w), np.float32)
+        assert self.lib.oracle_gray_u8(_p(rgb), w, h, _p(g), _p(f)) == 0
+        return g, f
+
+    def canvas_bbox(self, fw, fh, p, rw, rh):
+        mx, my, nw, nh = C.c_float(), C.c_float(), C.c_int(), C.c_int()
+        assert self.lib.oracle_canvas_bbox(fw, fh, (C.c_double * 8)(*p), rw, rh, C.byref(mx), C.byref(my), C.byref(nw), C.byref(nh)) == 0
+        return mx.value, my.value, nw.value, nh.value
+
+    def map_points(self, x, y, p, offx, offy):
+        x, y = np.array(x, np.float32), np.array(y, np.float32)
+        ix, iy = np.empty(x.size, np.int32), np.empty(x.size, np.int32)
+        self.lib.oracle_map_points(_p(x), _p(y), _p(ix), _p(iy), x.size, (C.c_double * 8)(*p), C.c_float(offx), C.c_float(offy))
+        return x, y, ix, iy
+
+    def shift_points(self, x, y, ox, oy):
+        x, y = np.array(x, np.float32), np.array(y, np.float32)
+        ix, iy = np.empty(x.size, np.int32), np.empty(x.size, np.int32)
+        self.lib.oracle_shift_points(_p(x), _p(y), _p(ix), _p(iy), x.size, int(ox), int(oy))
+        return x, y, ix, iy
+
     def synth(self, w, h, frame_id, dtype=np.uint8):
         out = np.empty((3, h, w), dtype)
         getattr(self.lib, "oracle_synth_" + ("u8" if dtype == np.uint8 else "f32"))(_p(out), w, h, int(frame_id))
@@ -258,6 +282,25 @@ class Reference:
         img = np.array(_img(img, np.uint8), copy=True)
         self.lib.ref_equalize_u8(_p(img), img.shape[2], img.shape[1])
         return img
+
+    def gray(self, rgb):
+        rgb = _img(rgb, np.uint8)
+        _, h, w = rgb.shape
+        g = np.empty((h, w), np.uint8)
+        assert self.lib.ref_gray_u8(_p(rgb), w, h, _p(g)) == 0
+        return g
+
+    def canvas(self, fw, fh, p, rw, rh):
+        mx, my, nw, nh = C.c_float(), C.c_float(), C.c_int(), C.c_int()
+        self.lib.ref_canvas(fw, fh, (C.c_double * 8)(*p), rw, rh, C.byref(mx), C.byref(my), C.byref(nw), C.byref(nh))
+        return mx.value, my.value, nw.value, nh.value
+
+    def update_features(self, x, y, p, offx, offy, ox, oy, by_offset):
+        x, y = np.array(x, np.float32), np.array(y, np.float32)
+        ix, iy = np.empty(x.size, np.int32), np.empty(x.size, np.int32)
+        self.lib.ref_update_features(_p(x), _p(y), _p(ix), _p(iy), x.size, (C.c_double * 8)(*p), C.c_float(offx), C.c_float(offy),
+                                     int(ox), int(oy), int(by_offset))
+        return x, y, ix, iy
 
     def cimg_blur(self, img, sigma=2.0, is_gaussian=True):
         img = np.array(img, dtype=np.float32, order="C", copy=True)

@@ -31,7 +31,7 @@ buf = np.zeros(16 << 20, np.uint8)
 rc = ref.ref_pipeline((sys.argv[3].rstrip("/") + "/").encode(), int(sys.argv[4]), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(w), C.byref(h))
 res = buf[: w.value * h.value * 3]
 print("RESULT " + json.dumps({"rc": rc, "w": w.value, "h": h.value, "sha256": hashlib.sha256(res.tobytes()).hexdigest(),
-                              "mean": float(res.mean()), "calls": [dropin.stitch_dropin_call_count(i) for i in range(5)]}))
+                              "mean": float(res.mean()), "calls": [dropin.stitch_dropin_call_count(i) for i in range(6)]}))
 '''
 
 
@@ -47,6 +47,6 @@ def test_reference_control_flow_on_hip_kernels(n):
     r = json.loads(line[7:])
     run = J["runs"][str(n)]
     assert r["rc"] == 0 and [3, r["h"], r["w"]] == run["final_shape"]
-    # project once per frame, warp/move/blend once per stitched neighbour, equalise once
-    assert r["calls"] == [n, n - 1, n - 1, n - 1, 1], r["calls"]
+    # project and gray once per frame, warp/move/blend once per stitched neighbour, equalise once
+    assert r["calls"] == [n, n - 1, n - 1, n - 1, 1, n], r["calls"]
     assert r["sha256"] == run["final_sha256"], (r["mean"], run["final_mean"])

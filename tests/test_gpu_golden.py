@@ -286,3 +286,17 @@ def test_fused_sweep_under_concurrent_load(st, gpu, oracle):
                 assert np.array_equal(got.view(np.uint32), refs[s_ * B + q].view(np.uint32)), (rep, s_, q)
     for p in plans:
         p.close()
+
+
+def test_gray_and_fused_projection(st, gpu, oracle, J, frames):
+    """toGrayScale + SIFT float staging, stand-alone and fused into the projection kernel."""
+    for f, e, eg in zip(frames, J["project_input"], J["gray_input"]):
+        proj, g, gf = st.capi.project_gray(f)
+        assert sha(proj) == e["sha256"] and sha(g) == eg["sha256"]
+        assert np.array_equal(gf, g.astype(np.float32))
+        g2, gf2 = st.capi.gray(proj)
+        assert np.array_equal(g2, g) and np.array_equal(gf2, gf)
+    img = oracle.synth(301, 97, 12)
+    og, ogf = oracle.gray(img)
+    g, gf = st.capi.gray(img)
+    assert np.array_equal(g, og) and np.array_equal(gf, ogf)

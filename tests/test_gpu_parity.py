@@ -219,6 +219,9 @@ def test_fused_sweep_modes_agree(st, gpu, oracle, mode, dtype, monkeypatch):
     plan = capi.Plan(700, 448)
     assert plan.fused_sweep_levels == 0  # auto: only levels of at least 1024 x 1024
     plan.close()
-    plan = capi.Plan(6144, 4096)
+    plan = capi.Plan(6144, 4096, max_pairs=2)
     assert plan.fused_sweep_levels == 2
+    plan.close()
+    plan = capi.Plan(2048, 1024)  # a lone pair is faster with separate sweeps
+    assert plan.fused_sweep_levels == 0
     plan.close()

@@ -45,3 +45,20 @@ def test_bmp_roundtrip(tmp_path):
         assert np.array_equal(bmp.load_bmp(p), img)
     g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "input", "1.bmp")
     assert bmp.load_bmp(g).shape == (3, 512, 384)
+
+
+def test_canvas_bbox_and_feature_updates_are_host_arithmetic(st, oracle):
+    """SURVEY.md 8(f) row 2 (ImageProcess.cpp:206-216, 622-640): computed on the host inside the library -- no
+    device needed -- and equal to the oracle / the reference's recorded canvases."""
+    import json
+    J = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")))
+    for e in J["canvas"]:
+        got = st.capi.canvas_bbox(e["fw"], e["fh"], e["p"], e["rw"], e["rh"])
+        assert list(got) == e["out"] == list(oracle.canvas_bbox(e["fw"], e["fh"], e["p"], e["rw"], e["rh"]))
+    rng = np.random.default_rng(5)
+    p = [0.9724, -0.0398, 0.000149, 206.67, 0.00141, 1.00076, -1.2e-06, 4.55]
+    x, y = rng.uniform(0, 384, 300).astype(np.float32), rng.uniform(0, 512, 300).astype(np.float32)
+    for a, b in zip(st.capi.map_points(x, y, p, -230.579239, -4.68064785), oracle.map_points(x, y, p, -230.579239, -4.68064785)):
+        assert np.array_equal(a, b)
+    for a, b in zip(st.capi.shift_points(x, y, -230, -4), oracle.shift_points(x, y, -230, -4)):
+        assert np.array_equal(a, b)

@@ -193,3 +193,12 @@ def test_oracle_is_clean_under_asan_ubsan():
     root = os.path.dirname(HERE)
     r = subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "sanitize-check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sanitize-check ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_gray_of_projected_inputs(oracle, J, frames):
+    for f, e in zip(frames, J["gray_input"]):
+        g, gf = oracle.gray(oracle.project(f))
+        assert sha(g) == e["sha256"] and int(g.sum()) == e["sum"]
+        assert np.array_equal(gf, g.astype(np.float32))
+    for e in J["canvas"]:
+        assert list(oracle.canvas_bbox(e["fw"], e["fh"], e["p"], e["rw"], e["rh"])) == e["out"]

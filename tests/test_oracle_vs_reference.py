@@ -126,3 +126,23 @@ def test_bbox(oracle, ref):
     corners = [oracle.map_xy(np.float32(x), np.float32(y), p) for x in (0, 383) for y in (0, 511)]
     assert mn_x == min(c[0] for c in corners) and mx_x == max(c[0] for c in corners)
     assert mn_y == min(c[1] for c in corners) and mx_y == max(c[1] for c in corners)
+
+
+def test_gray_bbox_features(oracle, ref):
+    """toGrayScale, canvas sizing, feature updates."""
+    rng = np.random.default_rng(7)
+    for f in range(3):
+        img = oracle.synth(123, 77, 40 + f)
+        g, gf = oracle.gray(img)
+        assert np.array_equal(g, ref.gray(img)) and np.array_equal(gf, g.astype(np.float32))
+    for _ in range(100):
+        p = [1 + rng.normal() * 0.05, rng.normal() * 0.05, rng.normal() * 2e-4, rng.normal() * 300,
+             rng.normal() * 0.05, 1 + rng.normal() * 0.05, rng.normal() * 2e-5, rng.normal() * 20]
+        fw, fh, rw, rh = (int(v) for v in rng.integers(50, 900, 4))
+        assert oracle.canvas_bbox(fw, fh, p, rw, rh) == ref.canvas(fw, fh, p, rw, rh)
+    p = [0.9724, -0.0398, 0.000149, 206.67, 0.00141, 1.00076, -1.2e-06, 4.55]
+    x, y = rng.uniform(0, 384, 200).astype(np.float32), rng.uniform(0, 512, 200).astype(np.float32)
+    a, b = oracle.map_points(x, y, p, -230.579239, -4.68064785), ref.update_features(x, y, p, -230.579239, -4.68064785, 0, 0, False)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))
+    a, b = oracle.shift_points(x, y, -230, -4), ref.update_features(x, y, p, 0, 0, -230, -4, True)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))
