@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frame", type=int, default=4096, help="frame edge of the CPU baseline's bounded sample")
     ap.add_argument("--no-kernel-events", action="store_true", help="time without per-launch HIP events")
+    ap.add_argument("--pixel", choices=["f32", "u8"], default="f32", help="frame pixel type (f32 = the metric; u8 = the reference's own contract)")
     ap.add_argument("--no-single", action="store_true", help="skip the single-pair-in-flight latency measurement")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
@@ -125,6 +126,8 @@ def main():
     F = args.frame
     cw, ch = pipeline.config_canvas(F)
     K, W, B, S = args.steps, args.warmup, args.batch, args.streams
+    tdt = torch.float32 if args.pixel == "f32" else torch.uint8
+    px_bytes = 4 if args.pixel == "f32" else 1
 
     # S "lanes": each lane = one batched plan (B pairs per launch sequence) on its own HIP stream, so that the
     # latency-bound small pyramid levels of one batch overlap the bandwidth-bound sweeps of the other.
@@ -139,14 +142,14 @@ def main():
             items = []
             for q in range(B):
                 i = (first + (ln * n_distinct + j) * B + q) % 32
-                items.append((capi.dev_synth(F, F, 2 * i + 1, torch.float32, dev), pipeline.config_map(i, F), 0.0, 0.0,
-                              capi.dev_synth(F, F, 2 * i, torch.float32, dev), 0, 0))
+                items.append((capi.dev_synth(F, F, 2 * i + 1, tdt, dev), pipeline.config_map(i, F), 0.0, 0.0,
+                              capi.dev_synth(F, F, 2 * i, tdt, dev), 0, 0))
             batches.append(items)
         lanes.append({
             "plan": capi.Plan(cw, ch, max_pairs=B),
             "stream": torch.cuda.Stream(device=dev),
             "batches": batches,
-            "outs": [[torch.empty((3, ch, cw), dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(2)],
+            "outs": [[torch.empty((3, ch, cw), dtype=tdt, device=dev) for _ in range(B)] for _ in range(2)],
             # N>1: finished mosaics travel as unsigned char (the reference's output type) through pipeline.MosaicGather
             # -- the class the gloo tests cover -- asynchronously: the gather of step k overlaps the kernels of step k+1
             "gather": pipeline.MosaicGather((B, 3, ch, cw), dev, world, rank, slots=2, force_collective=force_dist) if use_dist else None,
@@ -161,7 +164,10 @@ def main():
             if L["gather"] is not None:
                 slot = L["gather"].input_slot(k)
                 for q in range(n):
-                    capi.dev_quantize(outs[q], slot[q])
+                    if tdt == torch.float32:
+                        capi.dev_quantize(outs[q], slot[q])
+                    else:
+                        slot[q].copy_(outs[q])
                 L["gather"].submit(k)
 
     def drain():
@@ -239,13 +245,14 @@ def main():
     if rank == 0:
         mpix_pair = cw * ch / 1e6
         value = mpix_pair * K * B * S * world / elapsed
-        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, 4, plan.fused_sweep_levels)
+        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, px_bytes, plan.fused_sweep_levels)
         line = {
-            "metric": "warp+blend MPix/s at 4096x4096x3 f32", "value": round(value, 2), "unit": "MPix/s",
+            "metric": "warp+blend MPix/s at 4096x4096x3 f32" if args.pixel == "f32" else "warp+blend MPix/s at 4096x4096x3 u8", "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 accumulators)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (f64 accumulators)" if args.pixel == "f32" else "u8 frames, f32 pyramids (f64 accumulators)",
             "data": "synthetic",
-            "config": {"workload": f"config 2 pairs ({F}x{F}x3 f32 frames -> {cw}x{ch}x3 f32 mosaic: warp + move + "
+            "config": {"workload": f"config 2 pairs ({F}x{F}x3 {args.pixel} frames -> {cw}x{ch}x3 {args.pixel} mosaic: warp + move + "
                                    f"{plan.levels}-level multi-band blend); per GPU per step {S} batches of {B} independent pairs, "
                                    f"each batch one launch sequence on its own HIP stream (config 4's per-GPU shard); canvas pixels counted",
                        "frame": [F, F, 3], "canvas": [cw, ch, 3], "levels": plan.levels, "pairs_per_batch": B,
@@ -296,7 +303,7 @@ def main():
         L = lanes[0]
         last = W + PILOT + 2 * K - 1
         own = L["gather"].out[last % 2][rank]
-        ok = all(torch.equal(own[q], capi.dev_quantize(L["outs"][last % 2][q])) for q in range(B))
+        ok = all(torch.equal(own[q], capi.dev_quantize(L["outs"][last % 2][q]) if tdt == torch.float32 else L["outs"][last % 2][q]) for q in range(B))
         print(f"[gather check] own mosaics in the gathered block: {'ok' if ok else 'MISMATCH'}", file=sys.stderr)
     for L in lanes:
         L["plan"].close()
