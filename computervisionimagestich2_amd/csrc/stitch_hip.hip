@@ -192,7 +192,6 @@ struct stitch_plan {
     u64* wf_yg = nullptr;
     size_t wf_yg_bytes = 0;
     unsigned* wf_ctrl = nullptr;   // per level one band-queue head (16 words apart), then the abort flag
-    unsigned wf_epoch = 0;
     unsigned long long* wf_dbg = nullptr;  // STITCH_WAVEFRONT_STAMP=1: [2048][8] segment cycle sums (diagnostics)
     unsigned* h_wf_abort = nullptr;  // pinned copy of the abort flag of the last call
     float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
@@ -252,7 +251,7 @@ int launch_check(const char* what) {
 // REDUCE for every level (ImageProcess.cpp:705-715): blur(G_l) into T, decimate T into G_{l+1}.
 int run_reduce(stitch_plan* p, int n, hipStream_t s) {
     const int np = 7 * n;  // planes in flight: every launch covers all pairs of the batch
-    if (p->wf_levels > 0) HIPCHK(hipMemsetAsync(p->wf_ctrl, 0, sizeof(unsigned) * WF_CTRL_WORDS, s));  // tile-queue heads + abort flag
+    if (p->wf_levels > 0) k_clear_words<<<1, 256, 0, s>>>((u64*)p->wf_ctrl, WF_CTRL_WORDS / 2);  // band-queue heads + abort flag
     for (int l = 0; l + 1 < p->L; ++l) {
         const Level& a = p->lv[l];
         const Level& b = p->lv[l + 1];
@@ -280,11 +279,11 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s) {
             wf.NR = (a.h + TS - 1) / TS;
             wf.NC = (a.w + TS - 1) / TS;
             wf.NP = np;
-            if (++p->wf_epoch > 0xFFFFEu) {  // tags would repeat: clear the granules and start over
-                HIPCHK(hipMemsetAsync(p->wf_yg, 0, p->wf_yg_bytes, s));
-                p->wf_epoch = 1;
-            }
-            wf.epoch = p->wf_epoch;
+            // every polled word is cleared in front of the launch (never told apart by a per-launch argument: a captured
+            // graph replays frozen arguments, and stale tags from the previous replay would match at once)
+            const size_t gran_words = (size_t)wf.NP * wf.NC * WF_GRAN * WAVE;
+            k_clear_words<<<(int)std::min<size_t>((gran_words + 255) / 256, 2048), 256, 0, s>>>(p->wf_yg, gran_words);
+            wf.epoch = 1;
             wf.mask_l0 = mk.enabled;
             const long ntiles = (long)wf.NP * wf.NR;  // one persistent wavefront per row band
             // the x-sweep state lives in state[0 .. 4*lines); the y state the kernel leaves goes behind it

@@ -1429,6 +1429,12 @@ __global__ __launch_bounds__(256) void k_synth(PX* __restrict__ dst, int w, int 
 
 // float -> unsigned char by C-cast truncation: what `return expand;` does at ImageProcess.cpp:772 through
 // CImg<unsigned char>(const CImg<float>&) (CImg.h:11167-11182).  Values are in [0,255] after the collapse clamp.
+// Zeroes `n` 64-bit words (hand-off granules, queue heads, abort flag).  A kernel rather than hipMemsetAsync so that a
+// captured HIP graph orders it like every other node of the sequence.
+__global__ __launch_bounds__(256) void k_clear_words(u64* __restrict__ p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void k_quantize(const float* __restrict__ src, uint8_t* __restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {

@@ -288,6 +288,54 @@ def test_fused_sweep_under_concurrent_load(st, gpu, oracle):
         p.close()
 
 
+def test_captured_graph_replays_follow_their_inputs(st, gpu, oracle):
+    """stitch_dev_pairs_* is capture-safe: its launch sequence (fused sweep included) recorded once into a HIP graph and
+    replayed on NEW frame contents in the same buffers gives the oracle's result for the new contents, every time.  Nothing
+    may survive from the captured or the previous run: hand-off tags, band-queue heads and the abort flag are cleared by
+    kernels of the sequence itself, not told apart by per-launch arguments (which a replay freezes)."""
+    import torch
+    from computervisionimagestich2_amd import capi
+    fw, fh, cw, ch = 1500, 1100, 2200, 1100
+    B = 2
+    plan = capi.Plan(cw, ch, max_pairs=B)
+    assert plan.fused_sweep_levels >= 1
+    P = [[1.0, 0.002, 1e-6, -700.0 - 8.0 * i, -0.001, 1.0, 5e-7, 1.5] for i in range(B)]
+    items = [(torch.zeros((3, fh, fw), dtype=torch.float32, device=gpu), P[i], 0.0, 0.0,
+              torch.zeros((3, fh, fw), dtype=torch.float32, device=gpu), 0, 0,
+              torch.empty((3, ch, cw), dtype=torch.float32, device=gpu)) for i in range(B)]
+
+    def load(seed):
+        refs = []
+        for i, it in enumerate(items):
+            A, Bf = oracle.synth(fw, fh, seed + 2 * i, np.float32), oracle.synth(fw, fh, seed + 2 * i + 1, np.float32)
+            rc, ref = oracle.pair(Bf, P[i], 0.0, 0.0, A, 0, 0, cw, ch)
+            assert rc == 0
+            refs.append(ref)
+            it[0].copy_(torch.from_numpy(Bf))
+            it[4].copy_(torch.from_numpy(A))
+            it[7].fill_(-1.0)
+        torch.cuda.synchronize()
+        return refs
+
+    load(0)
+    s, g = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        plan.pairs(items)  # warm: nothing is allocated or compiled inside the capture
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            plan.pairs(items)
+    for rep, seed in enumerate((0, 10, 20, 10)):
+        refs = load(seed)
+        with torch.cuda.stream(s):
+            g.replay()
+        torch.cuda.synchronize()
+        for i in range(B):
+            plan.status(i)
+            got = items[i][7].cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), refs[i].view(np.uint32)), (rep, i)
+    plan.close()
+
+
 def test_gray_and_fused_projection(st, gpu, oracle, J, frames):
     """toGrayScale + SIFT float staging, stand-alone and fused into the projection kernel."""
     for f, e, eg in zip(frames, J["project_input"], J["gray_input"]):
