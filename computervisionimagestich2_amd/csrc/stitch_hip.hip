@@ -196,6 +196,7 @@ struct stitch_plan {
     unsigned* h_wf_abort = nullptr;  // pinned copy of the abort flag of the last call
     float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
     bool mask_opt = false;  // level-0 mask handled implicitly (Van Vliet, level-0 height a multiple of 64)
+    bool src_fuse = false;  // pairs: level-0 planes evaluated from the frames by their consumers, k_compose never runs
     SeamDev* d_seam = nullptr;
     SeamDev* h_seam = nullptr;  // pinned
     hipStream_t last_stream = nullptr;
@@ -249,7 +250,8 @@ int launch_check(const char* what) {
 }
 
 // REDUCE for every level (ImageProcess.cpp:705-715): blur(G_l) into T, decimate T into G_{l+1}.
-int run_reduce(stitch_plan* p, int n, hipStream_t s) {
+template <typename PX>
+int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, bool src) {
     const int np = 7 * n;  // planes in flight: every launch covers all pairs of the batch
     if (p->wf_levels > 0) k_clear_words<<<1, 256, 0, s>>>((u64*)p->wf_ctrl, WF_CTRL_WORDS / 2);  // band-queue heads + abort flag
     for (int l = 0; l + 1 < p->L; ++l) {
@@ -270,7 +272,10 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s) {
             const int nb = (int)((lines + TS - 1) / TS);
             {
                 StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
-                k_vv_x_fwd<<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk);
+                if (src && l == 0)
+                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa);
+                else
+                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{});
             }
             Wavefront wf{};
             wf.yg = p->wf_yg;
@@ -309,7 +314,10 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s) {
                 const int nb = (int)((lines + TS - 1) / TS);
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
-                    k_vv_x_fwd<<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk);
+                    if (src && l == 0)
+                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa);
+                else
+                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{});
                 }
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
@@ -352,7 +360,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s) {
 }
 
 template <typename OUT>
-int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s) {
+int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s, const PairArgs<OUT>& pa, bool src) {
     const int L = p->L;
     {
         const Level& t = p->lv[L - 1];
@@ -367,22 +375,25 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s)
         ExpandTab tb{a.ix, a.ax, a.iy, a.ay};
         if (l == 0)  // level 0: the mask is the seam's step function itself (never read from memory)
             k_collapse<OUT, true><<<grid_xy(a.w, (a.h + CROWS - 1) / CROWS, n), 256, 0, s>>>(
-                a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, tb, outs, a.w, (size_t)a.w * a.h, p->d_seam);
+                a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, tb, outs, a.w, (size_t)a.w * a.h, p->d_seam, pa,
+                src ? 1 : 0);
         else {
             OutPtrs<float> eo{};
             eo.p[0] = a.e;
             k_collapse<float, false><<<grid_xy(a.pitch, (a.h + CROWS - 1) / CROWS, n), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w,
-                                                                              nx.h, nx.pitch, nx.ps, tb, eo, a.pitch, a.ps, nullptr);
+                                                                              nx.h, nx.pitch, nx.ps, tb, eo, a.pitch, a.ps, nullptr,
+                                                                              NoPairArgs{}, 0);
         }
     }
     return launch_check("collapse");
 }
 
-int run_seam_mask(stitch_plan* p, int n, hipStream_t s) {
+template <typename PX>
+int run_seam_mask(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, bool src) {
     const Level& a = p->lv[0];
     {
         StageTimer t(p, s, STITCH_K_SEAM, 0);
-        k_seam<<<n, 1024, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam);
+        k_seam<PX><<<n, 1024, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam, pa, src ? 1 : 0);
     }
     if (!p->mask_opt) {
         StageTimer t(p, s, STITCH_K_MASK, 0);
@@ -410,11 +421,12 @@ int dev_blend(stitch_plan* p, const PX* d_a, const PX* d_b, PX* d_out, void* str
         StageTimer t(p, s, STITCH_K_COMPOSE, 0);
         k_load_canvases<PX><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(d_a, d_b, a.g, a.w, a.h, a.pitch, a.ps);
     }
-    if ((rc = run_seam_mask(p, 1, s))) return rc;
-    if ((rc = run_reduce(p, 1, s))) return rc;
+    const PairArgs<PX> none{};  // dense canvases: level 0 is in memory
+    if ((rc = run_seam_mask<PX>(p, 1, s, none, false))) return rc;
+    if ((rc = run_reduce<PX>(p, 1, s, none, false))) return rc;
     OutPtrs<PX> outs{};
     outs.p[0] = d_out;
-    if ((rc = run_collapse<PX>(p, 1, outs, s))) return rc;
+    if ((rc = run_collapse<PX>(p, 1, outs, s, none, false))) return rc;
     p->last_stream = s;
     p->pending = true;
     p->last_n = 1;
@@ -451,13 +463,20 @@ int dev_pairs(stitch_plan* p, const stitch_pair_desc* d, int n, void* stream) {
     hipStream_t s = as_stream(stream);
     const Level& a = p->lv[0];
     int rc;
+    // source-fused: level 0 is a function of the frames, evaluated by its three consumers through an index plane
+    bool src = p->src_fuse;
+    for (int i = 0; i < n; ++i)  // 32-bit element indices and byte offsets into one channel plane
+        src = src && (unsigned long long)d[i].fw * d[i].fh * sizeof(PX) < 0xfffffff0ULL && (unsigned long long)d[i].mw * d[i].mh * sizeof(PX) < 0xfffffff0ULL;
     {
         StageTimer t(p, s, STITCH_K_COMPOSE, 0);
-        k_compose<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps);
+        if (src)
+            k_src_index<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps);
+        else
+            k_compose<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps);
     }
-    if ((rc = run_seam_mask(p, n, s))) return rc;
-    if ((rc = run_reduce(p, n, s))) return rc;
-    if ((rc = run_collapse<PX>(p, n, outs, s))) return rc;
+    if ((rc = run_seam_mask<PX>(p, n, s, pa, src))) return rc;
+    if ((rc = run_reduce<PX>(p, n, s, pa, src))) return rc;
+    if ((rc = run_collapse<PX>(p, n, outs, s, pa, src))) return rc;
     p->last_stream = s;
     p->pending = true;
     p->last_n = n;
@@ -906,6 +925,10 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     p->side = reinterpret_cast<float*>(base + side_off);
     // implicit level-0 mask: needs both Van Vliet sweeps at level 0 and 64-row blocks that do not straddle planes
     p->mask_opt = !p->no_fuse && o.blur_kind == 0 && !p->blur_skip && L >= 2 && v0.w > 1 && v0.h > 1 && (v0.h % 64) == 0;
+    {
+        const char* e = getenv("STITCH_NO_SRC_FUSE");  // A/B and tests: keep S1 as its own kernel (k_compose)
+        p->src_fuse = p->mask_opt && !(e && atoi(e) != 0);
+    }
     // the slack rows and pitch padding are read by partial tiles: give them defined (zero) contents once
     if (hipMemset(p->arena, 0, off) != hipSuccess || hipHostMalloc((void**)&p->h_seam, sizeof(SeamDev) * B) != hipSuccess) {
         stitch_plan_destroy(p);

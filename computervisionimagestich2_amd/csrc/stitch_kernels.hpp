@@ -183,6 +183,158 @@ struct PairArgs {
     float offx[MAXB], offy[MAXB];
 };
 
+// Range-checked gathers of input samples: a raw buffer descriptor over one channel plane; a byte offset beyond the
+// plane (the index plane's "outside") reads as 0, which is the reference's untouched zero canvas.
+template <typename PX>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const PX* plane, size_t elems) {
+    // the inputs ARE wave-uniform (kernel arguments indexed by block-derived scalars); readfirstlane makes that provable,
+    // otherwise every buffer load is wrapped in a waterfall loop
+    const unsigned long long a = reinterpret_cast<unsigned long long>(plane);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned bytes = __builtin_amdgcn_readfirstlane((unsigned)(elems * sizeof(PX)));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<PX*>(((unsigned long long)hi << 32) | lo), (short)0, (int)bytes, 0x00020000);
+}
+template <typename PX>
+__device__ __forceinline__ float buf_px(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
+template <>
+__device__ __forceinline__ float buf_px<float>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+template <>
+__device__ __forceinline__ float buf_px<uint8_t>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return (float)__builtin_amdgcn_raw_buffer_load_b8(r, byte_off, 0, 0);
+}
+// the same loads, value left as raw bits (converted where it is consumed, so that nothing waits on the load early)
+template <typename PX>
+__device__ __forceinline__ float buf_raw(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
+template <>
+__device__ __forceinline__ float buf_raw<float>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+template <>
+__device__ __forceinline__ float buf_raw<uint8_t>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, byte_off, 0, 0));
+}
+template <typename PX>
+__device__ __forceinline__ float raw_to_px(float raw);
+template <>
+__device__ __forceinline__ float raw_to_px<float>(float raw) {
+    return raw;
+}
+template <>
+__device__ __forceinline__ float raw_to_px<uint8_t>(float raw) {
+    return (float)__float_as_uint(raw);
+}
+// "outside": a byte offset no plane reaches (the host keeps planes below 0xfffffff0 bytes), aligned for the access
+template <typename PX>
+__device__ __forceinline__ constexpr unsigned off_outside() {
+    return 0u - (unsigned)sizeof(PX);
+}
+
+// The level-0 planes of one pair as a FUNCTION of the inputs -- exactly the values k_compose stores (planes 0..2 the
+// warped frame, 3..5 the moved mosaic, 0 where the reference leaves its zeroed canvas untouched).  The consumers of
+// level 0 (seam scan, causal x sweep, level-0 collapse) evaluate it in place when the plan runs "source-fused", so the
+// six level-0 planes are never written to or read from HBM.  The double-precision map is evaluated once per canvas
+// pixel by k_src_index, which leaves the byte offset of frame sample (nx, ny) within a channel plane (or "outside") in
+// the slot of level-0 plane 0; the three channel sweeps and the collapse gather through that index.  use_src = 0: the planes are in memory (k_compose ran).
+template <typename PX>
+struct PairSrc {
+    const PX* __restrict__ frame;
+    const PX* __restrict__ mosaic;
+    MapP map;
+    int fw, fh, mw, mh, ox, oy;
+    float offx, offy;
+    size_t fpl, mpl;
+    __device__ __forceinline__ PairSrc(const PairArgs<PX>& pa, int pr)
+        : frame(pa.frame[pr]), mosaic(pa.mosaic[pr]), map(pa.map[pr]), fw(pa.fw[pr]), fh(pa.fh[pr]), mw(pa.mw[pr]), mh(pa.mh[pr]),
+          ox(pa.ox[pr]), oy(pa.oy[pr]), offx(pa.offx[pr]), offy(pa.offy[pr]), fpl((size_t)pa.fw[pr] * pa.fh[pr]),
+          mpl((size_t)pa.mw[pr] * pa.mh[pr]) {}
+    __device__ __forceinline__ bool frame_at(int x, int y, size_t& so) const {
+        int nx, ny;
+        if (!map_to_src(map, (float)x + offx, (float)y + offy, fw, fh, nx, ny)) return false;
+        so = (size_t)ny * fw + nx;
+        return true;
+    }
+    __device__ __forceinline__ bool mosaic_at(int x, int y, size_t& so) const {
+        const long long mx = (long long)x + ox, my = (long long)y + oy;
+        if (mx < 0 || mx >= mw || my < 0 || my >= mh) return false;
+        so = (size_t)my * mw + mx;
+        return true;
+    }
+    __device__ __forceinline__ float frame_val(size_t so, int c) const { return (float)px_store<PX>(warp_tap((float)frame[so + c * fpl])); }
+    __device__ __forceinline__ float mosaic_val(size_t so, int c) const { return (float)mosaic[so + c * mpl]; }
+    // plane q (0..5) at canvas pixel (x, y), 0 <= x < cw
+    __device__ __forceinline__ float plane(int q, int x, int y) const {
+        size_t so;
+        if (q < 3) return frame_at(x, y, so) ? frame_val(so, q) : 0.f;
+        return mosaic_at(x, y, so) ? mosaic_val(so, q - 3) : 0.f;
+    }
+};
+
+struct NoPairArgs {};  // levels >= 1 carry no pair description
+template <typename OUT, bool DENSE>
+struct CollapseSrc {
+    typedef NoPairArgs type;
+};
+template <typename OUT>
+struct CollapseSrc<OUT, true> {
+    typedef PairArgs<OUT> type;
+};
+// What one block of the causal x sweep needs of the pair when level 0 is source-fused: a range-checked descriptor of
+// its channel plane of the frame (q < 3, gathered through the index plane) or of the mosaic (a pure shift).
+struct XShift {
+    int mw, mh, ox, oy;
+};
+template <typename PX>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const PairArgs<PX>& pa, int pr, int q) {
+    const bool fr = q < 3;
+    const PX* base = fr ? pa.frame[pr] : pa.mosaic[pr];
+    const size_t elems = fr ? (size_t)pa.fw[pr] * pa.fh[pr] : (size_t)pa.mw[pr] * pa.mh[pr];
+    return plane_rsrc(base + (size_t)(fr ? q : (q < 6 ? q - 3 : 0)) * elems, elems);
+}
+template <typename PX>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x_rsrc(const NoPairArgs&, int, int) {
+    return plane_rsrc<PX>(nullptr, 0);
+}
+template <typename PX>
+__device__ __forceinline__ XShift x_shift(const PairArgs<PX>& pa, int pr) {
+    return XShift{pa.mw[pr], pa.mh[pr], pa.ox[pr], pa.oy[pr]};
+}
+template <typename PX>
+__device__ __forceinline__ XShift x_shift(const NoPairArgs&, int) {
+    return XShift{0, 0, 0, 0};
+}
+// mosaic byte offset of canvas (x, y) = row part + column part; either part 0xffffffff = outside (a valid part is
+// below 0xfffffff0).  Branch-free.
+template <typename PX>
+__device__ __forceinline__ unsigned mosaic_col(const XShift& m, int x, int w) {
+    const long long mx = (long long)x + m.ox;
+    const bool ok = x < w && mx >= 0 && mx < m.mw;
+    return ok ? (unsigned)mx * (unsigned)sizeof(PX) : 0xffffffffu;
+}
+template <typename PX>
+__device__ __forceinline__ unsigned mosaic_row(const XShift& m, int y) {
+    const long long my = (long long)y + m.oy;
+    const bool ok = my >= 0 && my < m.mh;
+    const unsigned r = (unsigned)my * (unsigned)m.mw * (unsigned)sizeof(PX);
+    return ok ? r : 0xffffffffu;
+}
+template <typename PX>
+__device__ __forceinline__ unsigned mosaic_offset(unsigned row, unsigned col) {
+    return (row == 0xffffffffu || col == 0xffffffffu) ? off_outside<PX>() : row + col;
+}
+
+template <typename PX>
+__global__ __launch_bounds__(256) void k_src_index(PairArgs<PX> pa, float* __restrict__ g0_all, int cw, int ch, int pitch, size_t ps) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, pr = blockIdx.z;
+    if (x >= pitch) return;
+    unsigned v = off_outside<PX>();
+    int nx, ny;
+    if (x < cw && map_to_src(pa.map[pr], (float)x + pa.offx[pr], (float)y + pa.offy[pr], pa.fw[pr], pa.fh[pr], nx, ny))
+        v = ((unsigned)ny * (unsigned)pa.fw[pr] + (unsigned)nx) * (unsigned)sizeof(PX);  // the host checked that a plane fits 32 bits
+    reinterpret_cast<unsigned*>(g0_all + (size_t)pr * 7 * ps)[(size_t)y * pitch + x] = v;
+}
+
 template <typename PX>
 __global__ __launch_bounds__(256) void k_compose(PairArgs<PX> pa, float* __restrict__ g0_all, int cw, int ch, int pitch,
                                                  size_t ps) {
@@ -238,20 +390,35 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+template <typename PX>
 __global__ __launch_bounds__(1024) void k_seam(const float* __restrict__ g0_all, int cw, int ch, int pitch, size_t ps,
-                                               int seam_rule, SeamDev* __restrict__ out_all) {
+                                               int seam_rule, SeamDev* __restrict__ out_all, PairArgs<PX> pa, int use_src) {
     __shared__ int red[4][16];
     const int mid = ch / 2;
     const float* g0 = g0_all + (size_t)blockIdx.x * 7 * ps;  // one workgroup per pair
     SeamDev* out = out_all + blockIdx.x;
     const float* a0 = g0 + (size_t)mid * pitch;
     const float* b0 = a0 + 3 * ps;
+    const PairSrc<PX> src(pa, blockIdx.x);
     int s_a = 0, n_a = 0, s_o = 0, n_o = 0;
     for (int x = threadIdx.x; x < cw; x += blockDim.x) {
-        bool a_on = a0[x] != 0.f, b_on = b0[x] != 0.f;
-        if (seam_rule) {
-            a_on = a_on && a0[x + ps] != 0.f && a0[x + 2 * ps] != 0.f;
-            b_on = b_on && b0[x + ps] != 0.f && b0[x + 2 * ps] != 0.f;
+        bool a_on, b_on;
+        if (use_src) {  // source-fused plan: the middle row straight from the inputs
+            size_t fo = 0, mo = 0;
+            const bool fin = src.frame_at(x, mid, fo), min_ = src.mosaic_at(x, mid, mo);
+            a_on = fin && src.frame_val(fo, 0) != 0.f;
+            b_on = min_ && src.mosaic_val(mo, 0) != 0.f;
+            if (seam_rule) {
+                a_on = a_on && src.frame_val(fo, 1) != 0.f && src.frame_val(fo, 2) != 0.f;
+                b_on = b_on && src.mosaic_val(mo, 1) != 0.f && src.mosaic_val(mo, 2) != 0.f;
+            }
+        } else {
+            a_on = a0[x] != 0.f;
+            b_on = b0[x] != 0.f;
+            if (seam_rule) {
+                a_on = a_on && a0[x + ps] != 0.f && a0[x + 2 * ps] != 0.f;
+                b_on = b_on && b0[x + ps] != 0.f && b0[x + 2 * ps] != 0.f;
+            }
         }
         if (a_on) {
             s_a += x;
@@ -386,10 +553,65 @@ __device__ __forceinline__ void tile_store_rows(float* __restrict__ base, int pi
             *reinterpret_cast<f4*>(p + (size_t)(4 * i) * pitch) = *reinterpret_cast<const f4*>(t + (4 * i) * TP);
 }
 
+// Source-fused level 0: plane byte offsets of one 64x64 tile in tile_load's element-to-lane layout (or "outside"),
+// and the gather through them.  k_compose's two stores: the warped sample goes through the degenerate bilinear call,
+// the moved one is a copy.
+template <typename PX>
+__device__ __forceinline__ void mosaic_indices(const XShift& ms, int c0, int lane, int y0, int w, f4 nidx[16]) {
+    const int c = c0 + ((lane & 15) << 2);
+    const unsigned c0i = mosaic_col<PX>(ms, c, w), c1i = mosaic_col<PX>(ms, c + 1, w), c2i = mosaic_col<PX>(ms, c + 2, w),
+                   c3i = mosaic_col<PX>(ms, c + 3, w);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const unsigned row = mosaic_row<PX>(ms, y0 + (lane >> 4) + 4 * i);
+        f4 v;
+        v.x = __uint_as_float(mosaic_offset<PX>(row, c0i));
+        v.y = __uint_as_float(mosaic_offset<PX>(row, c1i));
+        v.z = __uint_as_float(mosaic_offset<PX>(row, c2i));
+        v.w = __uint_as_float(mosaic_offset<PX>(row, c3i));
+        nidx[i] = v;
+    }
+}
+template <typename PX>
+__device__ __forceinline__ float src_px(__amdgpu_buffer_rsrc_t rs, bool warped, unsigned byte_off) {
+    const float v = buf_px<PX>(rs, byte_off);
+    return warped ? (float)px_store<PX>(warp_tap(v)) : v;
+}
+template <typename PX>
+__device__ __forceinline__ void src_gather(__amdgpu_buffer_rsrc_t rs, const f4 nidx[16], f4 pre[16]) {  // raw bits
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const f4 id = nidx[i];
+        f4 v;
+        v.x = buf_raw<PX>(rs, __float_as_uint(id.x));
+        v.y = buf_raw<PX>(rs, __float_as_uint(id.y));
+        v.z = buf_raw<PX>(rs, __float_as_uint(id.z));
+        v.w = buf_raw<PX>(rs, __float_as_uint(id.w));
+        pre[i] = v;
+    }
+}
+template <typename PX>
+__device__ __forceinline__ void src_finish(bool warped, f4 pre[16]) {  // raw bits -> the value k_compose would have stored
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        f4 v = pre[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = raw_to_px<PX>(v[j]);
+            v[j] = warped ? (float)px_store<PX>(warp_tap(t)) : t;
+        }
+        pre[i] = v;
+    }
+}
+
 // `lines` = rows of all planes stacked (plane stride = pitch*h, so line L starts at L*pitch); the buffers are
 // allocated with 64 spare rows so that a partial last block may touch rows >= lines without leaving them.
+// Level 0 of a source-fused plan (use_src; needs mk.enabled, i.e. a level height that is a multiple of 64): the input
+// tile is not read from `in` but evaluated from the pair's frames (PairSrc), so S1 never materialises.
+template <typename PX, bool SRC>
 __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, float* __restrict__ out, int w, int pitch,
-                                                  long lines, VVK k, double* __restrict__ state, MaskL0 mk) {
+                                                  long lines, VVK k, double* __restrict__ state, MaskL0 mk,
+                                                  typename CollapseSrc<PX, SRC>::type pa) {
     __shared__ __attribute__((aligned(16))) float tile[TS * TP];
     const int lane = threadIdx.x;
     const long line0 = (long)blockIdx.x * TS, line = line0 + lane;
@@ -399,6 +621,7 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
     const bool live = line < lines;
     bool gen_mask = false;  // wave-uniform: this block's 64 lines are rows of a level-0 mask plane
     SeamDev sd;
+    int src_q = 0, src_y0 = 0, src_pr = 0;  // wave-uniform: plane, first row and pair of this block (use_src)
     if (mk.enabled) {
         const long plane = line0 / mk.h;
         if (plane % 7 == 6) {
@@ -406,7 +629,18 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
             gen_mask = true;
             sd = mk.seam[plane / 7];
         }
+        src_q = (int)(plane % 7);
+        src_pr = (int)(plane / 7);
+        src_y0 = (int)(line0 % mk.h);
     }
+    const bool gen_frame = SRC && !gen_mask && src_q < 3, gen_mosaic = SRC && !gen_mask && src_q >= 3;
+    const __amdgpu_buffer_rsrc_t rs = x_rsrc<PX>(pa, src_pr, src_q);
+    const XShift ms = x_shift<PX>(pa, src_pr);
+    // rows src_y0.. of the pair's index plane (the slot of level-0 plane 0)
+    const float* idx_rows = in + ((size_t)src_pr * 7 * mk.h + src_y0) * pitch;
+    // Element indices of the next tile, produced one tile ahead of the gather that consumes them: loaded from the index
+    // plane (frame channels) or computed (the mosaic is a pure shift).
+    f4 nidx[SRC ? 16 : 1];
     auto gen_tile = [&](int c0, f4 pre[16]) {
         f4 v;
         const int c = c0 + ((lane & 15) << 2);
@@ -418,21 +652,41 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
         for (int i = 0; i < 16; ++i) pre[i] = v;
     };
     double iplus = 0.0;  // CImg.h:34906
-    if (live) iplus = gen_mask ? (double)mask_step(sd, w - 1) : (double)in[(size_t)line * pitch + (w - 1)];
+    if (live)
+        iplus = gen_mask     ? (double)mask_step(sd, w - 1)
+                : gen_frame  ? (double)src_px<PX>(rs, true, reinterpret_cast<const unsigned*>(idx_rows)[(size_t)lane * pitch + (w - 1)])
+                : gen_mosaic ? (double)src_px<PX>(rs, false, mosaic_offset<PX>(mosaic_row<PX>(ms, src_y0 + lane), mosaic_col<PX>(ms, w - 1, w)))
+                             : (double)in[(size_t)line * pitch + (w - 1)];
     double v1 = 0, v2 = 0, v3 = 0;
     f4 pre[16];
-    if (gen_mask)
-        gen_tile(0, pre);
-    else
-        tile_load(ib, pitch, 0, lane, pre);
+// tile T into `pre`; a source-fused block gathers through the indices produced during the previous fetch, then produces the next
+#define STITCH_X_FETCH(T)                                                      \
+    do {                                                                       \
+        if (gen_mask)                                                          \
+            gen_tile((T) * TS, pre);                                           \
+        else if constexpr (SRC) {                                              \
+            src_gather<PX>(rs, nidx, pre);                                     \
+            if ((T) + 1 < ntiles) {                                            \
+                if (gen_frame)                                                 \
+                    tile_load(idx_rows, pitch, ((T) + 1) * TS, lane, nidx);    \
+                else                                                           \
+                    mosaic_indices<PX>(ms, ((T) + 1) * TS, lane, src_y0, w, nidx); \
+            }                                                                  \
+        } else                                                                 \
+            tile_load(ib, pitch, (T) * TS, lane, pre);                         \
+    } while (0)
+    if constexpr (SRC) {
+        if (gen_frame)
+            tile_load(idx_rows, pitch, 0, lane, nidx);
+        else if (gen_mosaic)
+            mosaic_indices<PX>(ms, 0, lane, src_y0, w, nidx);
+    }
+    STITCH_X_FETCH(0);
     for (int t = 0; t < ntiles; ++t) {
+        if constexpr (SRC)
+            if (!gen_mask) src_finish<PX>(gen_frame, pre);
         tile_to_lds(tile, lane, pre);
-        if (t + 1 < ntiles) {
-            if (gen_mask)
-                gen_tile((t + 1) * TS, pre);
-            else
-                tile_load(ib, pitch, (t + 1) * TS, lane, pre);
-        }
+        if (t + 1 < ntiles) STITCH_X_FETCH(t + 1);
         __syncthreads();  // one wave per workgroup: orders the tile writes before the per-lane row reads
         float* row = tile + lane * TP;
         const int jmax = min(TS, w - t * TS);
@@ -476,6 +730,8 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
         state[3 * lines + line] = iplus;
     }
 }
+
+#undef STITCH_X_FETCH
 
 __device__ __forceinline__ void triggs(const VVK& k, double iplus, double& v1, double& v2, double& v3, float& first) {
     // CImg.h:34911-34922
@@ -1222,11 +1478,44 @@ struct OutPtrs {
 #define STITCH_CROWS 8
 #endif
 constexpr int CROWS = STITCH_CROWS;
+// G_0 of a source-fused plan: evaluated from the pair's frames; otherwise read from the level's planes.
+template <typename OUT>
+__device__ __forceinline__ void level_ab(const PairArgs<OUT>& pa, int pr, int use_src, const float* g, size_t o, size_t ps, int x, int y,
+                                         float a[3], float b[3]) {
+    if (use_src) {  // branch-free: clamped addresses, zero selected afterwards
+        const PairSrc<OUT> src(pa, pr);
+        const unsigned fo = reinterpret_cast<const unsigned*>(g)[o];  // k_src_index's byte offset in the slot of plane 0
+        const bool fin = fo != off_outside<OUT>();
+        size_t mo = 0;
+        const bool min_ = src.mosaic_at(x, y, mo);
+        mo = min_ ? mo : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float fa = src.frame_val((fin ? fo : 0u) / sizeof(OUT), c), fb = src.mosaic_val(mo, c);
+            a[c] = fin ? fa : 0.f;
+            b[c] = min_ ? fb : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[c] = g[o + c * ps];
+            b[c] = g[o + (3 + c) * ps];
+        }
+    }
+}
+__device__ __forceinline__ void level_ab(const NoPairArgs&, int, int, const float* g, size_t o, size_t ps, int, int, float a[3], float b[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a[c] = g[o + c * ps];
+        b[c] = g[o + (3 + c) * ps];
+    }
+}
 template <typename OUT, bool DENSE>
 __global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_all, int w, int h, int pitch, size_t ps,
                                                   const float* __restrict__ gn_all, const float* __restrict__ en_all, int sw,
                                                   int sh, int spitch, size_t sps, ExpandTab tb, OutPtrs<OUT> outs,
-                                                  int opitch, size_t ops, const SeamDev* __restrict__ seam_l0) {
+                                                  int opitch, size_t ops, const SeamDev* __restrict__ seam_l0,
+                                                  typename CollapseSrc<OUT, DENSE>::type pa, int use_src) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * CROWS, pr = blockIdx.z;
     if (x >= (DENSE ? w : pitch)) return;
     const float* g = g_all + (size_t)pr * 7 * ps;
@@ -1276,13 +1565,15 @@ __global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_al
         }
         const size_t o = (size_t)y * pitch + x;
         const float m = seam_l0 ? m_step : g[o + 6 * ps];
+        float ga[3], gb[3];
+        level_ab(pa, pr, use_src, g, o, ps, x, y, ga, gb);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float ea = y_nearest ? X1[c] : lerp_ref(ay, X1[c], X2[c]);
             const float eb = y_nearest ? X1[3 + c] : lerp_ref(ay, X1[3 + c], X2[3 + c]);
             const float ee = y_nearest ? X1[6 + c] : lerp_ref(ay, X1[6 + c], X2[6 + c]);
-            const float la = g[o + c * ps] - ea;
-            const float lb = g[o + (3 + c) * ps] - eb;
+            const float la = ga[c] - ea;
+            const float lb = gb[c] - eb;
             const float s_ = blend_ref(la, lb, m);
             float v = s_ + ee;
             if (v > 255.f)
