@@ -1515,14 +1515,14 @@ __global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_al
                                                   const float* __restrict__ gn_all, const float* __restrict__ en_all, int sw,
                                                   int sh, int spitch, size_t sps, ExpandTab tb, OutPtrs<OUT> outs,
                                                   int opitch, size_t ops, const SeamDev* __restrict__ seam_l0,
-                                                  typename CollapseSrc<OUT, DENSE>::type pa, int use_src) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * CROWS, pr = blockIdx.z;
+                                                  typename CollapseSrc<OUT, DENSE>::type pa, int use_src, int crows) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * crows, pr = blockIdx.z;
     if (x >= (DENSE ? w : pitch)) return;
     const float* g = g_all + (size_t)pr * 7 * ps;
     const float* gn = gn_all + (size_t)pr * 7 * sps;
     const float* en = en_all + (size_t)pr * 3 * sps;
     OUT* __restrict__ out = DENSE ? outs.p[pr] : outs.p[0] + (size_t)pr * 3 * ops;
-    const int y1 = min(y0 + CROWS, h);
+    const int y1 = min(y0 + crows, h);
     if (!DENSE && x >= w) {
         for (int y = y0; y < y1; ++y)
 #pragma unroll
