@@ -82,6 +82,7 @@ def lib():
         L.stitch_plan_destroy.restype = None
         L.stitch_plan_destroy.argtypes = [C.c_void_p]
         L.stitch_blend_opts_default.restype = None
+        L.stitch_bmp_file_bytes.restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -228,6 +229,59 @@ def project_gray(src, fov_deg=15.0):
     dst, g, f = np.empty_like(src), np.empty((h, w), np.uint8), np.empty((h, w), np.float32)
     _chk(lib().stitch_project_gray_u8(_p(src), w, h, C.c_float(fov_deg), _p(dst), _p(g), _p(f)))
     return dst, g, f
+
+
+class BmpInfo(C.Structure):
+    """stitch_bmp_info: what CImg's loader derives from the 54-byte header (CImg.h:48413-48441)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bpp", C.c_int32), ("top_down", C.c_int32),
+                ("data_pos", C.c_uint64), ("stride", C.c_uint64), ("data_bytes", C.c_uint64)]
+
+
+def bmp_parse(header, file_bytes):
+    """Header arithmetic of CImg's load_bmp on the first 54 bytes of a file of `file_bytes` bytes.  Host only."""
+    h = np.frombuffer(bytes(header[:54]), np.uint8)
+    bi = BmpInfo()
+    _chk(lib().stitch_bmp_parse(_p(h), C.c_size_t(int(file_bytes) if h.size >= 54 else h.size), C.byref(bi)))
+    return bi
+
+
+def bmp_decode(data):
+    """Bytes of a 24/32-bit BMP file -> planar (3,H,W) uint8 RGB, as CImg<unsigned char>::load_bmp gives it."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    bi = bmp_parse(buf[:54].tobytes(), buf.size)
+    out = np.empty((3, bi.height, bi.width), np.uint8)
+    _chk(lib().stitch_bmp_decode_u8(_p(buf), C.c_size_t(buf.size), _p(out)))
+    return out
+
+
+def bmp_encode(img):
+    """Planar (3,H,W) uint8 RGB -> the bytes CImg<unsigned char>::save_bmp writes."""
+    img = np.ascontiguousarray(_img(img), np.uint8)
+    _, h, w = img.shape
+    n = lib().stitch_bmp_file_bytes(w, h)
+    out = np.empty(n, np.uint8)
+    _chk(lib().stitch_bmp_encode_u8(_p(img), w, h, _p(out), C.c_size_t(n)))
+    return out.tobytes()
+
+
+def dev_bmp_decode(d_file, info, out=None):
+    """Device-resident file image (1-D uint8 tensor) -> planar (3,H,W) uint8 tensor; `info` from bmp_parse."""
+    import torch
+    assert d_file.is_cuda and d_file.dtype == torch.uint8 and d_file.is_contiguous()
+    out = torch.empty((3, info.height, info.width), dtype=torch.uint8, device=d_file.device) if out is None else out
+    _chk(lib().stitch_dev_bmp_decode_u8(_dp(d_file), C.c_size_t(d_file.numel()), C.byref(info), _dp(out), _stream()))
+    return out
+
+
+def dev_bmp_encode(d_img, out=None):
+    """Planar (3,H,W) uint8 tensor -> device-resident file image (1-D uint8 tensor), byte-identical to save_bmp."""
+    import torch
+    assert d_img.is_cuda and d_img.dtype == torch.uint8 and d_img.is_contiguous() and d_img.shape[0] == 3
+    _, h, w = d_img.shape
+    n = lib().stitch_bmp_file_bytes(int(w), int(h))
+    out = torch.empty(n, dtype=torch.uint8, device=d_img.device) if out is None else out
+    _chk(lib().stitch_dev_bmp_encode_u8(_dp(d_img), int(w), int(h), _dp(out), C.c_size_t(out.numel()), _stream()))
+    return out
 
 
 def canvas_bbox(fw, fh, p_fwd, result_w, result_h):

@@ -1112,6 +1112,138 @@ int stitch_dev_gray_u8(const uint8_t* d_rgb, int w, int h, uint8_t* d_gray, floa
     k_gray<<<eq_grid(n), 256, 0, as_stream(stream)>>>(d_rgb, n, d_gray, d_gray_f32);
     return launch_check("k_gray");
 }
+// ---- BMP <-> planar RGB ------------------------------------------------------------------------------------------
+static int le32(const uint8_t* p) { return (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+int stitch_bmp_parse(const uint8_t* f, size_t n, stitch_bmp_info* info) {
+    // CImg.h:48401-48441, for the layouts this path meets; every quantity as the reference derives it
+    if (!f || !info) return fail(STITCH_ERR_ARG, "bmp_parse: null argument");
+    if (n < 54 || f[0] != 'B' || f[1] != 'M') return fail(STITCH_ERR_ARG, "bmp_parse: not a BMP file");
+    int file_size = le32(f + 0x02);
+    const int offset = le32(f + 0x0A), header_size = le32(f + 0x0E), dx = le32(f + 0x12), dy = le32(f + 0x16), compression = le32(f + 0x1E),
+              bpp = f[0x1C] + (f[0x1D] << 8);
+    if (!file_size || file_size == offset) file_size = (int)n;
+    if (compression) return fail(STITCH_ERR_ARG, "bmp_parse: compressed BMP (compression=%d) is not supported", compression);
+    if (bpp != 24 && bpp != 32) return fail(STITCH_ERR_ARG, "bmp_parse: only 24- and 32-bit BMP is supported (bpp=%d)", bpp);
+    if (dx <= 0 || dy == 0 || dy == INT32_MIN) return fail(STITCH_ERR_ARG, "bmp_parse: bad size %d x %d", dx, dy);
+    const int h = dy < 0 ? -dy : dy;
+    const long long dx_bytes = (long long)dx * bpp / 8;
+    const int align_bytes = (int)((4 - dx_bytes % 4) % 4);
+    const unsigned long long want = (unsigned long long)h * (unsigned long long)(dx_bytes + align_bytes);
+    const unsigned long long avail_hdr = (unsigned long long)(long long)file_size - (unsigned long long)(long long)offset;
+    unsigned long long buf = std::min(want, avail_hdr);
+    long long pos = 54;
+    if (header_size > 40) pos += header_size - 40;
+    const long long xoffset = (long long)offset - 14 - header_size;
+    if (xoffset > 0) pos += xoffset;
+    if (pos < 0 || (unsigned long long)pos > n) return fail(STITCH_ERR_ARG, "bmp_parse: pixel data starts beyond the file");
+    buf = std::min(buf, (unsigned long long)n - (unsigned long long)pos);
+    info->width = dx;
+    info->height = h;
+    info->bpp = bpp;
+    info->top_down = dy < 0;
+    info->data_pos = (uint64_t)pos;
+    info->stride = (uint64_t)(dx_bytes + align_bytes);
+    info->data_bytes = buf;
+    return STITCH_OK;
+}
+size_t stitch_bmp_file_bytes(int w, int h) {
+    if (w <= 0 || h <= 0) return 0;
+    return 54 + (((size_t)3 * w + 3) & ~(size_t)3) * (size_t)h;
+}
+static int bmp_align(const void* p, unsigned long long pos) {
+    const unsigned long long a = (unsigned long long)reinterpret_cast<uintptr_t>(p) + pos;
+    return (a & 3) == 0 ? 4 : (a & 1) == 0 ? 2 : 1;
+}
+int stitch_dev_bmp_decode_u8(const uint8_t* d_file, size_t n, const stitch_bmp_info* bi, uint8_t* d_planar, void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_file || !bi || !d_planar) return fail(STITCH_ERR_ARG, "bmp_decode: null argument");
+    if (bi->width <= 0 || bi->height <= 0 || (bi->bpp != 24 && bi->bpp != 32) || bi->stride < (uint64_t)bi->width * (bi->bpp / 8) ||
+        (bi->stride & 3) || bi->data_pos > n || bi->data_bytes > n - bi->data_pos)
+        return fail(STITCH_ERR_ARG, "bmp_decode: inconsistent stitch_bmp_info (use stitch_bmp_parse)");
+    BmpGeom g{};
+    g.w = bi->width;
+    g.h = bi->height;
+    g.bp = bi->bpp / 8;
+    g.top_down = bi->top_down;
+    g.data_pos = bi->data_pos;
+    g.stride = bi->stride;
+    g.data_bytes = bi->data_bytes;
+    g.planar_vec = (g.w % 4 == 0) && (reinterpret_cast<uintptr_t>(d_planar) % 4 == 0);
+    const dim3 grid((g.w + BMP_SEG - 1) / BMP_SEG, g.h);
+    hipStream_t s = as_stream(stream);
+    switch (bmp_align(d_file, g.data_pos)) {  // stride and a segment's byte offset are multiples of 4
+        case 4: k_bmp_decode<4><<<grid, 256, 0, s>>>(d_file, g, d_planar); break;
+        case 2: k_bmp_decode<2><<<grid, 256, 0, s>>>(d_file, g, d_planar); break;
+        default: k_bmp_decode<1><<<grid, 256, 0, s>>>(d_file, g, d_planar); break;
+    }
+    return launch_check("k_bmp_decode");
+}
+int stitch_dev_bmp_encode_u8(const uint8_t* d_planar, int w, int h, uint8_t* d_file, size_t cap, void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    const size_t total = stitch_bmp_file_bytes(w, h);
+    if (!d_planar || !d_file || !total) return fail(STITCH_ERR_ARG, "bmp_encode: bad argument");
+    if (total > 0xffffffffULL) return fail(STITCH_ERR_ARG, "bmp_encode: %d x %d does not fit the format's 32-bit file size", w, h);
+    if (cap < total) return fail(STITCH_ERR_ARG, "bmp_encode: buffer of %zu bytes, file needs %zu", cap, total);
+    BmpGeom g{};
+    g.w = w;
+    g.h = h;
+    g.bp = 3;
+    g.stride = ((unsigned long long)3 * w + 3) & ~3ULL;
+    g.planar_vec = (w % 4 == 0) && (reinterpret_cast<uintptr_t>(d_planar) % 4 == 0);
+    BmpHeader hd{};  // CImg.h:52633-52664
+    const unsigned buf_size = (unsigned)(total - 54), file_size = (unsigned)total;
+    hd.b[0] = 'B';
+    hd.b[1] = 'M';
+    for (int i = 0; i < 4; ++i) {
+        hd.b[0x02 + i] = (uint8_t)(file_size >> (8 * i));
+        hd.b[0x12 + i] = (uint8_t)((unsigned)w >> (8 * i));
+        hd.b[0x16 + i] = (uint8_t)((unsigned)h >> (8 * i));
+        hd.b[0x22 + i] = (uint8_t)(buf_size >> (8 * i));
+    }
+    hd.b[0x0A] = 0x36;
+    hd.b[0x0E] = 0x28;
+    hd.b[0x1A] = 1;
+    hd.b[0x1C] = 24;
+    hd.b[0x27] = 0x1;
+    hd.b[0x2B] = 0x1;
+    const dim3 grid((unsigned)((g.stride + BMP_SEG * 3 - 1) / (BMP_SEG * 3)), h);
+    hipStream_t s = as_stream(stream);
+    switch (bmp_align(d_file, 54)) {
+        case 4: k_bmp_encode<4><<<grid, 256, 0, s>>>(d_planar, g, hd, d_file); break;
+        case 2: k_bmp_encode<2><<<grid, 256, 0, s>>>(d_planar, g, hd, d_file); break;
+        default: k_bmp_encode<1><<<grid, 256, 0, s>>>(d_planar, g, hd, d_file); break;
+    }
+    return launch_check("k_bmp_encode");
+}
+int stitch_bmp_decode_u8(const uint8_t* file, size_t n, uint8_t* planar) {
+    int rc = need_device();
+    if (rc) return rc;
+    stitch_bmp_info bi;
+    if ((rc = stitch_bmp_parse(file, n, &bi))) return rc;
+    if (!planar) return fail(STITCH_ERR_ARG, "bmp_decode: null output");
+    const size_t out = (size_t)3 * bi.width * bi.height;
+    DevBuf f, p;
+    if ((rc = f.alloc(n)) || (rc = p.alloc(out))) return rc;
+    HIPCHK(hipMemcpy(f.p, file, n, hipMemcpyHostToDevice));
+    if ((rc = stitch_dev_bmp_decode_u8(f.as<uint8_t>(), n, &bi, p.as<uint8_t>(), nullptr))) return rc;
+    HIPCHK(hipMemcpy(planar, p.p, out, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+int stitch_bmp_encode_u8(const uint8_t* planar, int w, int h, uint8_t* file, size_t cap) {
+    int rc = need_device();
+    if (rc) return rc;
+    const size_t total = stitch_bmp_file_bytes(w, h);
+    if (!planar || !file || !total) return fail(STITCH_ERR_ARG, "bmp_encode: bad argument");
+    if (cap < total) return fail(STITCH_ERR_ARG, "bmp_encode: buffer of %zu bytes, file needs %zu", cap, total);
+    DevBuf f, p;
+    if ((rc = f.alloc(total)) || (rc = p.alloc((size_t)3 * w * h))) return rc;
+    HIPCHK(hipMemcpy(p.p, planar, (size_t)3 * w * h, hipMemcpyHostToDevice));
+    if ((rc = stitch_dev_bmp_encode_u8(p.as<uint8_t>(), w, h, f.as<uint8_t>(), total, nullptr))) return rc;
+    HIPCHK(hipMemcpy(file, f.p, total, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
 int stitch_dev_project_gray_u8(const uint8_t* d_src, int w, int h, float fov_deg, uint8_t* d_projected, uint8_t* d_gray,
                                float* d_gray_f32, void* stream) {
     return dev_project<uint8_t>(d_src, w, h, fov_deg, d_projected, stream, d_gray, d_gray_f32);

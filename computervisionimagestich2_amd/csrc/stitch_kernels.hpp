@@ -91,6 +91,107 @@ __global__ __launch_bounds__(256) void k_gray(const uint8_t* __restrict__ rgb, s
     }
 }
 
+// ---- BMP <-> planar RGB (CImg.h:48395-48566 _load_bmp, :52614-52700 _save_bmp) ------------------------------
+// The on-disk format either side of the path: rows bottom-up (or top-down when the header height is negative), bytes
+// B G R [X], rows padded to 4 bytes.  One workgroup moves 1024 pixels of one file row; the file side is accessed in
+// A-byte units (A = the alignment the file position allows, usually 2 because pixel data starts at byte 54), staged
+// through LDS so that both the interleaved file bytes and the three planar rows are moved by coalesced accesses.
+struct BmpGeom {
+    int w, h, bp, top_down;  // bp = bytes per pixel in the file (3 or 4)
+    unsigned long long data_pos, stride, data_bytes;
+    int planar_vec;  // planar rows start 4-byte aligned (w % 4 == 0 and an aligned base): uchar4 accesses
+};
+constexpr int BMP_SEG = 1024;  // pixels per workgroup
+template <int A>
+struct BmpUnit;
+template <>
+struct BmpUnit<1> { typedef uint8_t type; };
+template <>
+struct BmpUnit<2> { typedef uint16_t type; };
+template <>
+struct BmpUnit<4> { typedef uint32_t type; };
+
+template <int A>
+__global__ __launch_bounds__(256) void k_bmp_decode(const uint8_t* __restrict__ file, BmpGeom g, uint8_t* __restrict__ planar) {
+    typedef typename BmpUnit<A>::type U;
+    __shared__ __attribute__((aligned(16))) uint8_t seg[BMP_SEG * 4];
+    const int x0 = blockIdx.x * BMP_SEG, r = blockIdx.y;  // r = row in file order
+    const int npx = min(BMP_SEG, g.w - x0), nbytes = npx * g.bp;
+    const unsigned long long row_off = (unsigned long long)r * g.stride + (unsigned long long)x0 * g.bp;  // within the pixel data
+    const uint8_t* src = file + g.data_pos + row_off;
+    for (int u = threadIdx.x; u * A < nbytes; u += 256) {
+        const unsigned long long o = row_off + (unsigned long long)u * A;
+        U v = 0;
+        if (o + A <= g.data_bytes)
+            v = reinterpret_cast<const U*>(src)[u];
+        else  // a file that ends early: the reference's zero-filled buffer (CImg.h:48445)
+            for (int k = 0; k < A; ++k)
+                if (o + k < g.data_bytes) v |= (U)((U)src[(size_t)u * A + k] << (8 * k));
+        reinterpret_cast<U*>(seg)[u] = v;
+    }
+    __syncthreads();
+    const int x = 4 * threadIdx.x;
+    if (x >= npx) return;
+    const int y = g.top_down ? r : g.h - 1 - r;  // CImg.h:48536 (rows arrive last-first), :48563 (mirror when dy < 0)
+    const size_t pl = (size_t)g.w * g.h, o = (size_t)y * g.w + x0 + x;
+    const uint8_t* p = seg + x * g.bp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {  // channel c = byte 2 - c of the pixel (CImg.h:48540-48542)
+        if (g.planar_vec) {
+            uchar4 v;
+            v.x = p[2 - c];
+            v.y = p[g.bp + 2 - c];
+            v.z = p[2 * g.bp + 2 - c];
+            v.w = p[3 * g.bp + 2 - c];
+            *reinterpret_cast<uchar4*>(planar + c * pl + o) = v;
+        } else
+            for (int j = 0; j < 4 && x + j < npx; ++j) planar[c * pl + o + j] = p[j * g.bp + 2 - c];
+    }
+}
+
+struct BmpHeader {
+    uint8_t b[56];
+};
+template <int A>
+__global__ __launch_bounds__(256) void k_bmp_encode(const uint8_t* __restrict__ planar, BmpGeom g, BmpHeader hdr, uint8_t* __restrict__ file) {
+    typedef typename BmpUnit<A>::type U;
+    __shared__ __attribute__((aligned(16))) uint8_t seg[BMP_SEG * 3 + 16];
+    const int x0 = blockIdx.x * BMP_SEG, r = blockIdx.y;
+    if (blockIdx.x == 0 && r == 0 && threadIdx.x < 54) file[threadIdx.x] = hdr.b[threadIdx.x];
+    const int y = g.h - 1 - r;  // bottom-up (CImg.h:52672-52674, :52698)
+    const size_t pl = (size_t)g.w * g.h;
+    {
+        const int x = x0 + 4 * threadIdx.x;
+        uint8_t px[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // pixels beyond the row stay 0 = the row padding
+        const size_t o = (size_t)y * g.w + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (g.planar_vec && x + 3 < g.w) {
+                const uchar4 v = *reinterpret_cast<const uchar4*>(planar + c * pl + o);
+                px[c][0] = v.x;
+                px[c][1] = v.y;
+                px[c][2] = v.z;
+                px[c][3] = v.w;
+            } else
+                for (int j = 0; j < 4; ++j)
+                    if (x + j < g.w) px[c][j] = planar[c * pl + o + j];
+        }
+        uint8_t* p = seg + 12 * threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p[3 * j] = px[2][j];
+            p[3 * j + 1] = px[1][j];
+            p[3 * j + 2] = px[0][j];
+        }
+    }
+    __syncthreads();
+    // bytes of this row segment in the file: up to the end of the row including its padding
+    const unsigned long long seg_off = (unsigned long long)x0 * 3;
+    const int nbytes = (int)min((unsigned long long)BMP_SEG * 3, g.stride - seg_off);
+    uint8_t* dst = file + 54 + (unsigned long long)r * g.stride + seg_off;
+    for (int u = threadIdx.x; u * A < nbytes; u += 256) reinterpret_cast<U*>(dst)[u] = reinterpret_cast<const U*>(seg)[u];
+}
+
 // ---- P1: cylindrical projection, Projection.cpp:20-73 ------------------------------------------------------
 // One output pixel (three channels) per work-item; r is computed on the host (tan).  Writes 0 where the
 // source coordinate falls outside, so no memset pass is needed.

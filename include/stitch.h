@@ -201,6 +201,22 @@ int stitch_dev_finish_u8(uint8_t *d_result, int w, int h, double num, double den
  * Either output may be NULL. */
 int stitch_gray_u8(const uint8_t *rgb, int w, int h, uint8_t *gray, float *gray_f32);
 int stitch_dev_gray_u8(const uint8_t *d_rgb, int w, int h, uint8_t *d_gray, float *d_gray_f32, void *stream);
+/* The on-disk format either side of the path: CImg<T>::load_bmp (CImg.h:48395-48566) reads the
+ * Input/ frames, save_bmp (CImg.h:52614-52700) writes the panorama.  Uncompressed 24- and 32-bit files (the reference's
+ * are 24-bit); palette, 16-bit and compressed files are refused with STITCH_ERR_ARG.  A file is one byte array.
+ * stitch_bmp_parse is host arithmetic on the 54-byte header (n = size of the whole file); decode writes planar RGB
+ * (3*width*height bytes), bytes the file lacks read as 0 exactly as the reference's zero-filled buffer does; encode
+ * writes the byte-identical file save_bmp would (stitch_bmp_file_bytes(w,h) bytes). */
+typedef struct stitch_bmp_info {
+    int32_t width, height, bpp, top_down;
+    uint64_t data_pos, stride, data_bytes; /* first pixel byte, bytes per file row, pixel bytes present */
+} stitch_bmp_info;
+int stitch_bmp_parse(const uint8_t *file_header54, size_t n, stitch_bmp_info *info);
+size_t stitch_bmp_file_bytes(int w, int h);
+int stitch_bmp_decode_u8(const uint8_t *file, size_t n, uint8_t *planar);
+int stitch_bmp_encode_u8(const uint8_t *planar, int w, int h, uint8_t *file, size_t cap);
+int stitch_dev_bmp_decode_u8(const uint8_t *d_file, size_t n, const stitch_bmp_info *info, uint8_t *d_planar, void *stream);
+int stitch_dev_bmp_encode_u8(const uint8_t *d_planar, int w, int h, uint8_t *d_file, size_t cap, void *stream);
 /* readFile's per-image chain in one kernel (ImageProcess.cpp:18-20): projection + gray + float staging. */
 int stitch_project_gray_u8(const uint8_t *src, int w, int h, float fov_deg, uint8_t *projected, uint8_t *gray,
                            float *gray_f32);

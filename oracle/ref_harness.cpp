@@ -209,3 +209,10 @@ REF_API int ref_load_bmp(const char *path, uint8_t *out, int cap, int *w, int *h
     if (out && (size_t)cap >= sz) std::memcpy(out, s.data(), sz);
     return 0;
 }
+
+// CImg<unsigned char>::save_bmp (CImg.h:52605) on a planar RGB image
+REF_API int ref_save_bmp(const uint8_t *planar, int w, int h, const char *path) {
+    U8Img s(planar, w, h, 1, 3, true);
+    s.save_bmp(path);
+    return 0;
+}

@@ -794,3 +794,101 @@ void oracle_synth_f32(float *dst, int w, int h, int f) {
         }
     }
 }
+
+/* ---- the on-disk format either side of the path -------------------------------------
+ * CImg<T>::_load_bmp (CImg.h:48395-48566) and _save_bmp (CImg.h:52614-52700), for the uncompressed 24- and
+ * 32-bit layouts (the reference's Input/ files and its result file are 24-bit).  File image = one byte array. */
+static int le32(const uint8_t *p) { return (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+
+int oracle_bmp_parse(const uint8_t *file, size_t n, oracle_bmp_info *info) {
+    if (!file || !info || n < 54) return ORACLE_ERR_ARG;
+    if (file[0] != 'B' || file[1] != 'M') return ORACLE_ERR_ARG; /* CImg.h:48404 */
+    int file_size = le32(file + 0x02);                             /* CImg.h:48413-48421 */
+    const int offset = le32(file + 0x0A), header_size = le32(file + 0x0E), dx = le32(file + 0x12), dy = le32(file + 0x16),
+              compression = le32(file + 0x1E), bpp = file[0x1C] + (file[0x1D] << 8);
+    if (!file_size || file_size == offset) file_size = (int)n;     /* CImg.h:48423-48427 */
+    if (compression) return ORACLE_ERR_ARG;                        /* CImg.h:48452-48462: external converter */
+    if (bpp != 24 && bpp != 32) return ORACLE_ERR_ARG;             /* palette / 16-bit layouts are not on this path */
+    if (dx <= 0 || dy == 0 || dy == INT32_MIN) return ORACLE_ERR_ARG;
+    const int h = dy < 0 ? -dy : dy;
+    const long long dx_bytes = (long long)dx * bpp / 8;            /* CImg.h:48431 */
+    const int align_bytes = (int)((4 - dx_bytes % 4) % 4);         /* CImg.h:48432 */
+    const unsigned long long want = (unsigned long long)h * (unsigned long long)(dx_bytes + align_bytes);
+    /* CImg.h:48435: min(rows * stride, (ulongT)file_size - offset); the subtraction is unsigned */
+    const unsigned long long avail_hdr = (unsigned long long)(long long)file_size - (unsigned long long)(long long)offset;
+    unsigned long long buf = want < avail_hdr ? want : avail_hdr;
+    /* position of the first pixel byte: 54, + header_size-40 if larger (CImg.h:48428), + xoffset if positive (:48440-41) */
+    long long pos = 54;
+    if (header_size > 40) pos += header_size - 40;
+    const long long xoffset = (long long)offset - 14 - header_size;
+    if (xoffset > 0) pos += xoffset;
+    if (pos < 0 || (unsigned long long)pos > n) return ORACLE_ERR_ARG;
+    const unsigned long long in_file = n - (unsigned long long)pos; /* fread stops at the end of the file */
+    if (buf > in_file) buf = in_file;
+    info->width = dx;
+    info->height = h;
+    info->bpp = bpp;
+    info->top_down = dy < 0;
+    info->data_pos = (uint64_t)pos;
+    info->stride = (uint64_t)(dx_bytes + align_bytes);
+    info->data_bytes = buf; /* bytes of pixel data actually present; the rest of the buffer reads as 0 (CImg.h:48445) */
+    return ORACLE_OK;
+}
+
+int oracle_bmp_decode_u8(const uint8_t *file, size_t n, uint8_t *planar) {
+    oracle_bmp_info bi;
+    int rc = oracle_bmp_parse(file, n, &bi);
+    if (rc) return rc;
+    const int w = bi.width, h = bi.height, bpp_bytes = bi.bpp / 8;
+    const size_t pl = (size_t)w * h;
+    for (int y = 0; y < h; ++y) {
+        /* the file's first row is the image's last (CImg.h:48536 walks y = height-1 .. 0); dy < 0 mirrors (:48563) */
+        const int img_y = bi.top_down ? y : h - 1 - y;
+        for (int x = 0; x < w; ++x)
+            for (int k = 0; k < 3; ++k) { /* bytes B, G, R -> channels 2, 1, 0 (CImg.h:48540-48542) */
+                const uint64_t o = (uint64_t)y * bi.stride + (uint64_t)x * bpp_bytes + k;
+                planar[(size_t)(2 - k) * pl + (size_t)img_y * w + x] = o < bi.data_bytes ? file[bi.data_pos + o] : 0;
+            }
+    }
+    return ORACLE_OK;
+}
+
+size_t oracle_bmp_file_bytes(int w, int h) {
+    if (w <= 0 || h <= 0) return 0;
+    const unsigned align = (4 - (3u * (unsigned)w) % 4) % 4; /* CImg.h:52635 */
+    return 54 + ((size_t)3 * w + align) * (size_t)h;
+}
+
+int oracle_bmp_encode_u8(const uint8_t *planar, int w, int h, uint8_t *file, size_t cap) {
+    const size_t total = oracle_bmp_file_bytes(w, h);
+    if (!planar || !file || !total || cap < total) return ORACLE_ERR_ARG;
+    const unsigned align = (4 - (3u * (unsigned)w) % 4) % 4;
+    const unsigned buf_size = (unsigned)(total - 54), file_size = (unsigned)total; /* CImg.h:52636-52637 */
+    memset(file, 0, 54);
+    file[0] = 'B';
+    file[1] = 'M';
+    for (int i = 0; i < 4; ++i) {
+        file[0x02 + i] = (uint8_t)(file_size >> (8 * i));
+        file[0x12 + i] = (uint8_t)((unsigned)w >> (8 * i));
+        file[0x16 + i] = (uint8_t)((unsigned)h >> (8 * i));
+        file[0x22 + i] = (uint8_t)(buf_size >> (8 * i));
+    }
+    file[0x0A] = 0x36; /* CImg.h:52643-52664 */
+    file[0x0E] = 0x28;
+    file[0x1A] = 1;
+    file[0x1C] = 24;
+    file[0x27] = 0x1;
+    file[0x2B] = 0x1;
+    const size_t pl = (size_t)w * h, stride = (size_t)3 * w + align;
+    for (int r = 0; r < h; ++r) { /* rows bottom-up, bytes B G R, zero padding (CImg.h:52690-52699) */
+        uint8_t *row = file + 54 + (size_t)r * stride;
+        const size_t src = (size_t)(h - 1 - r) * w;
+        for (int x = 0; x < w; ++x) {
+            row[3 * x] = planar[2 * pl + src + x];
+            row[3 * x + 1] = planar[pl + src + x];
+            row[3 * x + 2] = planar[src + x];
+        }
+        for (unsigned a = 0; a < align; ++a) row[(size_t)3 * w + a] = 0;
+    }
+    return ORACLE_OK;
+}

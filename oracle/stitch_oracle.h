@@ -16,6 +16,7 @@
  */
 #ifndef STITCH_ORACLE_H
 #define STITCH_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -95,6 +96,16 @@ int oracle_canvas_bbox(int fw, int fh, const double p_fwd[8], int result_w, int 
                        int *new_w, int *new_h);
 void oracle_map_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, const double p_fwd[8], float offx, float offy);
 void oracle_shift_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, int ox, int oy);
+/* BMP <-> planar RGB, CImg.h:48395-48566 (_load_bmp) and :52614-52700 (_save_bmp);
+ * uncompressed 24/32-bit only.  A file is one byte array. */
+typedef struct oracle_bmp_info {
+    int32_t width, height, bpp, top_down;
+    uint64_t data_pos, stride, data_bytes;
+} oracle_bmp_info;
+int oracle_bmp_parse(const uint8_t *file, size_t n, oracle_bmp_info *info);
+int oracle_bmp_decode_u8(const uint8_t *file, size_t n, uint8_t *planar);
+size_t oracle_bmp_file_bytes(int w, int h);
+int oracle_bmp_encode_u8(const uint8_t *planar, int w, int h, uint8_t *file, size_t cap);
 /* synthetic frame generator of SURVEY.md 8(d) */
 void oracle_synth_u8(uint8_t *dst, int w, int h, int frame_id);
 void oracle_synth_f32(float *dst, int w, int h, int frame_id);

@@ -47,6 +47,17 @@ ms = timeit(lambda: capi.dev_lummix(work, eq))
 res["lummix_u8"] = {"ms": ms, "MPix/s": P / ms / 1e3, "GB/s (9*P)": 9 * P / ms / 1e6}
 ms = timeit(lambda: capi.dev_finish(work, 19.0, 20.0, hist))
 res["finish_u8 (equalise+mix fused)"] = {"ms": ms, "MPix/s": P / ms / 1e3, "GB/s (9*P)": 9 * P / ms / 1e6}
+# the on-disk format either side of the path: 24-bit BMP <-> planar RGB, device-resident
+for (w, h, tag) in ((F, F, "frame 4096x4096"), (cw, ch, "mosaic 6144x4096")):
+    img = capi.dev_synth(w, h, 1, torch.uint8, dev)
+    fil = capi.dev_bmp_encode(img)
+    bi = capi.bmp_parse(fil[:54].cpu().numpy().tobytes(), fil.numel())
+    back = torch.empty_like(img)
+    ms = timeit(lambda: capi.dev_bmp_encode(img, fil))
+    res[f"bmp_encode_u8 {tag}"] = {"ms": ms, "MPix/s": w * h / ms / 1e3, "GB/s (file + planar bytes)": (fil.numel() + img.numel()) / ms / 1e6}
+    ms = timeit(lambda: capi.dev_bmp_decode(fil, bi, back))
+    res[f"bmp_decode_u8 {tag}"] = {"ms": ms, "MPix/s": w * h / ms / 1e3, "GB/s (file + planar bytes)": (fil.numel() + img.numel()) / ms / 1e6}
+    assert torch.equal(back, img)
 # host-pointer pair (PCIe inclusive)
 import numpy as np, time
 A = capi.dev_synth(F, F, 0, torch.float32, dev).cpu().numpy()

@@ -186,6 +186,22 @@ def main():
             if w * h <= 9000:
                 Z[f"blend_{w}x{h}_{int(a_left)}_out"] = out
 
+    # ---- the on-disk format: CImg::save_bmp bytes and CImg::load_bmp of layout variants --------
+    # inputs are recipes (synthetic frame ids, oracle_lib.make_bmp knobs); hashes are of the reference's outputs
+    from oracle_lib import make_bmp
+    tmp = tempfile.mkdtemp()
+    J["bmp_save"] = [{"w": w, "h": h, "frame": f, "file_sha256": hashlib.sha256(R.save_bmp_bytes(O.synth(w, h, f), tmp)).hexdigest()}
+                     for (w, h, f) in [(257, 129, 5), (5, 3, 5), (1, 7, 5), (64, 64, 5), (1025, 4, 5), (1368, 17, 2)]]
+    J["bmp_save"].append({"input": 1, "file_sha256": hashlib.sha256(R.save_bmp_bytes(frames[0], tmp)).hexdigest(),
+                          "same_as_input_file": R.save_bmp_bytes(frames[0], tmp) == open(f"{REF_DIR}/Input/1.bmp", "rb").read()})
+    J["bmp_load"] = []
+    for (w, h) in [(257, 129), (5, 3), (1027, 3)]:
+        for kw in [dict(), dict(bpp=32), dict(top_down=True), dict(header_size=108), dict(extra_gap=10), dict(size_field=0),
+                   dict(truncate=7), dict(truncate=3 * w + 5), dict(bpp=32, top_down=True, header_size=124, extra_gap=3)]:
+            img = R.load_bmp_bytes(make_bmp(O.synth(w, h, 3), **kw), tmp)
+            J["bmp_load"].append({"w": w, "h": h, "frame": 3, "knobs": kw, "shape": list(img.shape), "sha256": sha(img)})
+    shutil.rmtree(tmp)
+
     np.savez_compressed(os.path.join(HERE, "golden.npz"), **Z)
     json.dump(J, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
     print("wrote", os.path.join(HERE, "golden.json"), os.path.getsize(os.path.join(HERE, "golden.json")), "bytes;",

@@ -27,6 +27,33 @@ class Seam(C.Structure):
         return (self.sum_a_x, self.n_a, self.sum_ov_x, self.n_ov, self.branch, self.start)
 
 
+class BmpInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bpp", C.c_int32), ("top_down", C.c_int32),
+                ("data_pos", C.c_uint64), ("stride", C.c_uint64), ("data_bytes", C.c_uint64)]
+
+
+def make_bmp(img, bpp=24, top_down=False, header_size=40, extra_gap=0, size_field=None, truncate=0, alpha=0x5A):
+    """A BMP file image (bytes) with the layout knobs CImg's loader distinguishes (CImg.h:48413-48441): bits per
+    pixel 24/32, negative height, a larger info header, a gap before the pixel data, the file-size field (None =
+    true size, 0 = "unknown"), and missing bytes at the end.  Test-side builder, independent of the encoders."""
+    import struct
+    img = np.asarray(img, np.uint8)
+    _, h, w = img.shape
+    bp = bpp // 8
+    stride = (w * bp + 3) & ~3
+    rows = np.zeros((h, stride), np.uint8)
+    px = np.full((h, w, bp), alpha, np.uint8)
+    px[:, :, 0], px[:, :, 1], px[:, :, 2] = img[2], img[1], img[0]
+    rows[:, : w * bp] = (px if top_down else px[::-1]).reshape(h, w * bp)
+    offset = 14 + header_size + extra_gap
+    total = offset + stride * h
+    hdr = b"BM" + struct.pack("<IHHI", total if size_field is None else size_field, 0, 0, offset)
+    info = struct.pack("<IiiHHIIiiII", header_size, w, -h if top_down else h, 1, bpp, 0, stride * h, 2835, 2835, 0, 0)
+    info += bytes((i * 7 + 3) & 0xFF for i in range(header_size - 40)) + bytes((i * 5 + 1) & 0xFF for i in range(extra_gap))
+    data = hdr + info + rows.tobytes()
+    return data[: len(data) - truncate] if truncate else data
+
+
 ROOT_OPTS = dict(sigma=2.0, blur_kind=0, level_rule=0, seam_rule=0)   # root variant (ImageProcess.cpp)
 EX6_OPTS = dict(sigma=2.0, blur_kind=1, level_rule=1, seam_rule=1)    # src/ex6 variant
 
@@ -223,6 +250,30 @@ class Oracle:
         getattr(self.lib, "oracle_synth_" + ("u8" if dtype == np.uint8 else "f32"))(_p(out), w, h, int(frame_id))
         return out
 
+    def bmp_decode(self, data):
+        """bytes of a BMP file -> (rc, planar (3,H,W) uint8 or None)"""
+        buf = np.frombuffer(bytes(data), np.uint8)
+        bi = BmpInfo()
+        self.lib.oracle_bmp_parse.restype = C.c_int
+        rc = self.lib.oracle_bmp_parse(_p(buf), C.c_size_t(buf.size), C.byref(bi))
+        if rc:
+            return rc, None
+        out = np.empty((3, bi.height, bi.width), np.uint8)
+        self.lib.oracle_bmp_decode_u8.restype = C.c_int
+        rc = self.lib.oracle_bmp_decode_u8(_p(buf), C.c_size_t(buf.size), _p(out))
+        return rc, out
+
+    def bmp_encode(self, img):
+        img = _img(img, np.uint8)
+        _, h, w = img.shape
+        self.lib.oracle_bmp_file_bytes.restype = C.c_size_t
+        n = self.lib.oracle_bmp_file_bytes(w, h)
+        out = np.empty(n, np.uint8)
+        self.lib.oracle_bmp_encode_u8.restype = C.c_int
+        rc = self.lib.oracle_bmp_encode_u8(_p(img), w, h, _p(out), C.c_size_t(n))
+        assert rc == 0, rc
+        return out.tobytes()
+
 
 def have_reference():
     return os.path.exists(REF_SO)
@@ -331,3 +382,18 @@ class Reference:
         rc = self.lib.ref_load_bmp(path.encode(), _p(buf), buf.size, C.byref(w), C.byref(h))
         assert rc == 0, rc
         return buf[:w.value * h.value * 3].reshape(3, h.value, w.value).copy()
+
+    def load_bmp_bytes(self, data, tmpdir):
+        """CImg's loader on a file image given as bytes (written to tmpdir first)."""
+        path = os.path.join(str(tmpdir), "ref_in.bmp")
+        with open(path, "wb") as f:
+            f.write(data)
+        return self.load_bmp(path)
+
+    def save_bmp_bytes(self, img, tmpdir):
+        """CImg<unsigned char>::save_bmp on a planar image -> the bytes of the file it wrote."""
+        img = _img(img, np.uint8)
+        path = os.path.join(str(tmpdir), "ref_out.bmp")
+        self.lib.ref_save_bmp(_p(img), img.shape[2], img.shape[1], path.encode())
+        with open(path, "rb") as f:
+            return f.read()

@@ -348,3 +348,20 @@ def test_gray_and_fused_projection(st, gpu, oracle, J, frames):
     og, ogf = oracle.gray(img)
     g, gf = st.capi.gray(img)
     assert np.array_equal(g, og) and np.array_equal(gf, ogf)
+
+
+def test_bmp_golden_on_device(st, gpu, J, frames):
+    """SURVEY.md 8(f) row 3 against the reference's own bytes (tests/golden: CImg::load_bmp / save_bmp outputs)."""
+    import hashlib
+    from computervisionimagestich2_amd import capi
+    from oracle_lib import Oracle, make_bmp
+    O = Oracle()
+    for e, f in zip(J["input"], frames):
+        got = capi.bmp_decode(open(os.path.join(G, e["file"]), "rb").read())
+        assert sha(got) == e["sha256"]
+    for e in J["bmp_load"]:
+        got = capi.bmp_decode(make_bmp(O.synth(e["w"], e["h"], e["frame"]), **e["knobs"]))
+        assert list(got.shape) == e["shape"] and sha(got) == e["sha256"], e
+    for e in J["bmp_save"]:
+        img = frames[e["input"] - 1] if "input" in e else O.synth(e["w"], e["h"], e["frame"])
+        assert hashlib.sha256(capi.bmp_encode(img)).hexdigest() == e["file_sha256"], e

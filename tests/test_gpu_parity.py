@@ -265,3 +265,58 @@ def test_source_fused_level0_edge_cases(st, gpu, oracle, dtype, seam_rule, no_sr
     plan.status(0)
     assert np.array_equal(out1[0].cpu().numpy().view(np.uint8), refs[1].view(np.uint8))
     plan.close()
+
+
+BMP_VARIANTS = [dict(), dict(bpp=32), dict(top_down=True), dict(header_size=108), dict(extra_gap=10), dict(size_field=0),
+                dict(truncate=7), dict(truncate="row"), dict(bpp=32, top_down=True, header_size=124, extra_gap=3), dict(extra_gap=1)]
+
+
+@pytest.mark.parametrize("w,h", [(257, 129), (5, 3), (1, 7), (64, 64), (2, 2), (1, 1), (1024, 5), (1025, 4), (2051, 3), (1368, 17)])
+def test_bmp_decode_encode(st, gpu, oracle, w, h):
+    """SURVEY.md 8(f) row 3: the on-disk format either side of the path.  Decode = CImg::load_bmp for every header
+    layout its 24/32-bit branch distinguishes (and files that end early), encode = the bytes CImg::save_bmp writes;
+    widths around the 1024-pixel workgroup segment and with every row padding; odd pixel-data alignment."""
+    import torch
+    from computervisionimagestich2_amd import capi
+    from oracle_lib import make_bmp
+    img = oracle.synth(w, h, 5)
+    for kw in BMP_VARIANTS:
+        kw = dict(kw)
+        if kw.get("truncate") == "row":
+            kw["truncate"] = 3 * w + 5
+        data = make_bmp(img, **kw)
+        if len(data) < 54:
+            continue
+        rc, ref = oracle.bmp_decode(data)
+        assert rc == 0
+        got = capi.bmp_decode(data)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (w, h, kw)
+        if not kw.get("truncate"):
+            assert np.array_equal(ref, img)
+    ref_file = oracle.bmp_encode(img)
+    assert capi.bmp_encode(img) == ref_file
+    # device-resident twins, and the round trip
+    d_file = capi.dev_bmp_encode(torch.from_numpy(img).to(gpu))
+    assert d_file.cpu().numpy().tobytes() == ref_file
+    back = capi.dev_bmp_decode(d_file, capi.bmp_parse(ref_file, len(ref_file)))
+    assert np.array_equal(back.cpu().numpy(), img)
+    # a file image that does not start on a 4-byte boundary of device memory
+    shifted = torch.empty(d_file.numel() + 1, dtype=torch.uint8, device=gpu)
+    shifted[1:].copy_(d_file)
+    back = capi.dev_bmp_decode(shifted[1:], capi.bmp_parse(ref_file, len(ref_file)))
+    assert np.array_equal(back.cpu().numpy(), img)
+
+
+def test_bmp_refusals(st, gpu):
+    from computervisionimagestich2_amd import capi
+    from oracle_lib import make_bmp
+    img = np.zeros((3, 4, 4), np.uint8)
+    good = bytearray(make_bmp(img))
+    for patch in [(0, b"XM"), (0x1C, bytes([8, 0])), (0x1E, bytes([1, 0, 0, 0])), (0x12, bytes([0, 0, 0, 0]))]:
+        bad = bytearray(good)
+        bad[patch[0]:patch[0] + len(patch[1])] = patch[1]
+        with pytest.raises(st.StitchError) as e:
+            capi.bmp_decode(bytes(bad))
+        assert e.value.code == st.capi.ERR_ARG
+    with pytest.raises(st.StitchError):
+        capi.bmp_decode(bytes(good[:40]))

@@ -202,3 +202,19 @@ def test_gray_of_projected_inputs(oracle, J, frames):
         assert np.array_equal(gf, g.astype(np.float32))
     for e in J["canvas"]:
         assert list(oracle.canvas_bbox(e["fw"], e["fh"], e["p"], e["rw"], e["rh"])) == e["out"]
+
+
+def test_bmp_golden(oracle, J, frames):
+    """The reference's own BMP bytes: its Input/ files decode to the frames CImg gave (golden 'input'), layout variants
+    decode to the hashes CImg::load_bmp produced, and encoding gives the hashes of the files CImg::save_bmp wrote."""
+    import hashlib
+    from oracle_lib import make_bmp
+    for e, f in zip(J["input"], frames):
+        rc, got = oracle.bmp_decode(open(os.path.join(G, e["file"]), "rb").read())
+        assert rc == 0 and sha(got) == e["sha256"] and np.array_equal(got, f)
+    for e in J["bmp_load"]:
+        rc, got = oracle.bmp_decode(make_bmp(oracle.synth(e["w"], e["h"], e["frame"]), **e["knobs"]))
+        assert rc == 0 and list(got.shape) == e["shape"] and sha(got) == e["sha256"], e
+    for e in J["bmp_save"]:
+        img = frames[e["input"] - 1] if "input" in e else oracle.synth(e["w"], e["h"], e["frame"])
+        assert hashlib.sha256(oracle.bmp_encode(img)).hexdigest() == e["file_sha256"], e

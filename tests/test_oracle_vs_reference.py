@@ -146,3 +146,20 @@ def test_gray_bbox_features(oracle, ref):
     assert all(np.array_equal(u, v) for u, v in zip(a, b))
     a, b = oracle.shift_points(x, y, -230, -4), ref.update_features(x, y, p, 0, 0, -230, -4, True)
     assert all(np.array_equal(u, v) for u, v in zip(a, b))
+
+
+@pytest.mark.parametrize("w,h", [(257, 129), (5, 3), (1, 7), (64, 64), (2, 2), (1027, 3), (1368, 17)])
+def test_bmp_load_save(oracle, ref, w, h, tmp_path):
+    """SURVEY.md 8(f) row 3: oracle_bmp_decode/encode against CImg::load_bmp / save_bmp for every 24/32-bit header
+    layout the loader distinguishes, including files that end early."""
+    from oracle_lib import make_bmp
+    img = oracle.synth(w, h, 3)
+    for kw in [dict(), dict(bpp=32), dict(top_down=True), dict(header_size=108), dict(extra_gap=10), dict(extra_gap=1), dict(size_field=0),
+               dict(size_field=60), dict(truncate=7), dict(truncate=3 * w + 5), dict(bpp=32, top_down=True, header_size=124, extra_gap=3)]:
+        data = make_bmp(img, **kw)
+        if len(data) < 54:
+            continue
+        rc, got = oracle.bmp_decode(data)
+        want = ref.load_bmp_bytes(data, tmp_path)
+        assert rc == 0 and got.shape == want.shape and np.array_equal(got, want), kw
+    assert oracle.bmp_encode(img) == ref.save_bmp_bytes(img, tmp_path)
