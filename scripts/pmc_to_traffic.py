@@ -3,9 +3,10 @@
 
 HBM bytes per kernel = 2*FETCH_SIZE + WRITE_SIZE, both counters in KiB.  The factor 2 on FETCH_SIZE is the gfx950
 correction of /opt/skills/guides/MI355X_MICROARCH.md ("FETCH_SIZE reports exactly half of the bytes of a wide
-coalesced streaming read"); it is checked here against a kernel whose bytes are known exactly (k_vv_x_fwd at level
-0 reads n_pairs*6 planes of the canvas and writes 7 -- the calibration line printed below).  Counters come from
-separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)."""
+coalesced streaming read"); it is checked here against a kernel whose bytes are known exactly: the level-0 launch of
+k_vv_xbyf reads and writes the same n_pairs*6 planes of T in place, so 2*FETCH_SIZE must come out equal to WRITE_SIZE
+(which needs no correction) -- the calibration line printed below.  Counters come from separate passes (FETCH_SIZE and
+WRITE_SIZE do not fit one pass)."""
 import collections
 import csv
 import glob
@@ -16,9 +17,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-steps_total = None  # derived below: k_compose runs once per step
+steps_total = None  # derived below: k_seam runs once per step
 
-GROUP = {"k_compose": "compose", "k_seam": "seam", "k_mask": "mask", "k_vv_x_fwd": "vv_x_fwd",
+GROUP = {"k_compose": "compose", "k_src_index": "compose", "k_seam": "seam", "k_mask": "mask", "k_vv_x_fwd": "vv_x_fwd",
          "k_vv_x_bwd": "vv_x_bwd", "k_vv_y_fwd": "vv_y_fwd", "k_vv_y_bwd_dec": "vv_y_bwd", "k_vv_y_bwd": "vv_y_bwd",
          "k_decimate": "decimate", "k_collapse<float, false>": "collapse", "k_collapse<float, true>": "collapse_l0",
          "k_collapse<unsigned char, true>": "collapse_l0", "k_blend_top": "collapse_top", "k_vv_xbyf<false>": "vv_xbyf",
@@ -50,7 +51,7 @@ def counter(name):
         mx[k] = max(mx[k], float(r["Counter_Value"]))
         cnt[k] += 1
     global steps_total
-    steps_total = cnt.get("k_compose", 0) or steps_total
+    steps_total = cnt.get("k_seam", 0) or steps_total
     return tot, mx
 
 
@@ -74,7 +75,8 @@ for g, e in out.items():
     e["hbm_bytes_per_launch"] = int(hbm / n) if n else None
     e["batch"] = batch
 out["_meta"] = {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, averaged over the run's steps",
-                "calibration_k_vv_x_fwd_level0": {"FETCH_SIZE_KiB_max": fmax.get("k_vv_x_fwd"), "WRITE_SIZE_KiB_max": wmax.get("k_vv_x_fwd")},
+                "calibration_k_vv_xbyf_level0": {"FETCH_SIZE_KiB_max": fmax.get("k_vv_xbyf<false>"), "WRITE_SIZE_KiB_max": wmax.get("k_vv_xbyf<false>"),
+                                                 "two_fetch_over_write": round(2 * fmax.get("k_vv_xbyf<false>", 0) / max(wmax.get("k_vv_xbyf<false>", 1), 1), 4)},
                 "source": os.path.relpath(src, ROOT), "batch": batch, "steps": steps_total}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 tot = sum(e["hbm_bytes_per_pair"] for g, e in out.items() if not g.startswith("_"))
