@@ -3,9 +3,9 @@
 
 HBM bytes per kernel = 2*FETCH_SIZE + WRITE_SIZE, both counters in KiB.  The factor 2 on FETCH_SIZE is the gfx950
 correction of /opt/skills/guides/MI355X_MICROARCH.md ("FETCH_SIZE reports exactly half of the bytes of a wide
-coalesced streaming read"); it is checked here against a kernel whose bytes are known exactly: the level-0 launch of
-k_vv_xbyf reads and writes the same n_pairs*6 planes of T in place, so 2*FETCH_SIZE must come out equal to WRITE_SIZE
-(which needs no correction) -- the calibration line printed below.  Counters come from separate passes (FETCH_SIZE and
+coalesced streaming read"); it is checked here against a kernel whose bytes are known exactly: the level-1 launch of
+k_vv_x_fwd<float, false> streams n_pairs*7 planes of 3072 x 2048 floats in and the same out, so 2*FETCH_SIZE and
+WRITE_SIZE (which needs no correction) must both come out at 7*n_pairs*3072*2048*4 bytes -- the calibration entry.  Counters come from separate passes (FETCH_SIZE and
 WRITE_SIZE do not fit one pass)."""
 import collections
 import csv
@@ -20,6 +20,8 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 steps_total = None  # derived below: k_seam runs once per step
 
 GROUP = {"k_compose": "compose", "k_src_index": "compose", "k_seam": "seam", "k_mask": "mask", "k_vv_x_fwd": "vv_x_fwd",
+         "k_vv_x_fwd<float, false>": "vv_x_fwd", "k_vv_x_fwd<float, true>": "vv_x_fwd", "k_vv_x_fwd<unsigned char, false>": "vv_x_fwd",
+         "k_vv_x_fwd<unsigned char, true>": "vv_x_fwd",
          "k_vv_x_bwd": "vv_x_bwd", "k_vv_y_fwd": "vv_y_fwd", "k_vv_y_bwd_dec": "vv_y_bwd", "k_vv_y_bwd": "vv_y_bwd",
          "k_decimate": "decimate", "k_collapse<float, false>": "collapse", "k_collapse<float, true>": "collapse_l0",
          "k_collapse<unsigned char, true>": "collapse_l0", "k_blend_top": "collapse_top", "k_vv_xbyf<false>": "vv_xbyf",
@@ -33,7 +35,7 @@ def kname(full):
     s = s[s.index("sk::") + 4:] if "sk::" in s else s
     if "(" in s:
         s = s[: s.index("(")]
-    if s.startswith("k_collapse<") or s.startswith("k_vv_xbyf<"):
+    if s.startswith("k_collapse<") or s.startswith("k_vv_xbyf<") or s.startswith("k_vv_x_fwd<"):
         return s
     return s[: s.index("<")] if "<" in s else s
 
@@ -75,8 +77,9 @@ for g, e in out.items():
     e["hbm_bytes_per_launch"] = int(hbm / n) if n else None
     e["batch"] = batch
 out["_meta"] = {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, averaged over the run's steps",
-                "calibration_k_vv_xbyf_level0": {"FETCH_SIZE_KiB_max": fmax.get("k_vv_xbyf<false>"), "WRITE_SIZE_KiB_max": wmax.get("k_vv_xbyf<false>"),
-                                                 "two_fetch_over_write": round(2 * fmax.get("k_vv_xbyf<false>", 0) / max(wmax.get("k_vv_xbyf<false>", 1), 1), 4)},
+                "calibration_k_vv_x_fwd_level1": {"FETCH_SIZE_KiB_max": fmax.get("k_vv_x_fwd<float, false>"),
+                                                  "WRITE_SIZE_KiB_max": wmax.get("k_vv_x_fwd<float, false>"),
+                                                  "expected_KiB_each_way": 7 * batch * 3072 * 2048 * 4 / 1024},
                 "source": os.path.relpath(src, ROOT), "batch": batch, "steps": steps_total}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 tot = sum(e["hbm_bytes_per_pair"] for g, e in out.items() if not g.startswith("_"))
