@@ -17,6 +17,9 @@
 //   ImageProcess::blendTwoImages(a, b)                                       ImageProcess.cpp:648-773  -> stitch_blend_u8
 //   equalization::equalization(CImg<uchar>&, int)                            equalization.cpp:4-25     -> stitch_equalize_u8
 //   ImageProcess::toGrayScale(const CImg<uchar>&)                            ImageProcess.cpp:27-40    -> stitch_gray_u8
+//   transfer::transfer(CImg<uchar>& src, CImg<uchar>& tem, CImg<uchar>& out) transfer.cpp:3-13         -> stitch_transfer_u8
+//     (dead code in the reference, ImageProcess.cpp:180-182; transfer.cpp itself needs the Win32 thread API, so with
+//      this definition the class becomes usable on Linux)
 //
 // How the definitions take effect is described in INTEGRATION.md: link-time replacement for Projection.o and
 // equalization.o; for the three ImageProcess members (same translation unit as the control flow) either the
@@ -35,7 +38,7 @@
 #include "stitch.h"
 
 namespace {
-int g_calls[6] = {0, 0, 0, 0, 0, 0};  // project, warp, move, blend, equalize, gray -- lets a harness prove which code ran
+int g_calls[7] = {0, 0, 0, 0, 0, 0, 0};  // project, warp, move, blend, equalize, gray, transfer -- lets a harness prove which code ran
 void check(int rc, const char* what) {
     if (rc == STITCH_OK) return;
     // The reference signals no errors on this path (degenerate inputs hang or crash it); the drop-in
@@ -44,8 +47,9 @@ void check(int rc, const char* what) {
 }
 }  // namespace
 
-// number of times each replaced function has run in this process (0 project, 1 warp, 2 move, 3 blend, 4 equalize, 5 gray)
-extern "C" int stitch_dropin_call_count(int which) { return which >= 0 && which < 6 ? g_calls[which] : -1; }
+// number of times each replaced function has run in this process (0 project, 1 warp, 2 move, 3 blend, 4 equalize, 5 gray,
+// 6 transfer)
+extern "C" int stitch_dropin_call_count(int which) { return which >= 0 && which < 7 ? g_calls[which] : -1; }
 
 CImg<unsigned char> Projection::imageProjection(const CImg<unsigned char>& src) {
     if (src.spectrum() != CHANNEL_NUM || src.depth() != 1) throw std::runtime_error("imageProjection: expected a 3-channel 2-D image");
@@ -108,4 +112,26 @@ equalization::equalization(CImg<unsigned char>& src, int mode) {
             std::cout << "ERROR mode input!" << std::endl;  // equalization.cpp:21
             break;
     }
+}
+
+// transfer.h is pulled in by ImageProcess.h.  The constructor is the class's whole public behaviour (transfer.cpp:3-13).
+transfer::transfer(CImg<unsigned char>& src, CImg<unsigned char>& tem, CImg<unsigned char>& output) {
+    if (src.spectrum() != 3 || tem.spectrum() != 3 || src.depth() != 1 || tem.depth() != 1)
+        throw std::runtime_error("transfer: expected 3-channel 2-D images");
+    ++g_calls[6];
+    CImg<unsigned char> res(src.width(), src.height(), 1, 3);
+    check(stitch_transfer_u8(src.data(), src.width(), src.height(), tem.data(), tem.width(), tem.height(), res.data(), nullptr),
+          "stitch_transfer_u8");
+    output = res;  // `output` may be `src` itself (ImageProcess.cpp:180)
+}
+
+// test hook: runs the class exactly as ImageProcess.cpp:180 would (output aliasing the source)
+extern "C" int stitch_dropin_transfer_in_place(unsigned char* src, int sw, int sh, const unsigned char* tem, int tw, int th) {
+    CImg<unsigned char> s(src, sw, sh, 1, 3, true), t(tem, tw, th, 1, 3);
+    try {
+        transfer tr(s, t, s);
+    } catch (const std::exception&) {
+        return -1;
+    }
+    return 0;
 }

@@ -231,6 +231,26 @@ def project_gray(src, fov_deg=15.0):
     return dst, g, f
 
 
+def transfer(src, tem):
+    """transfer::transfer (transfer.cpp:3-13,125-225): l-alpha-beta colour transfer of tem's statistics onto src
+    -> (out (3,H,W) uint8, stats float32[12] = mean/sd of src, mean/sd of tem)."""
+    src, tem = np.ascontiguousarray(_img(src), np.uint8), np.ascontiguousarray(_img(tem), np.uint8)
+    out, st = np.empty_like(src), np.zeros(12, np.float32)
+    _chk(lib().stitch_transfer_u8(_p(src), src.shape[2], src.shape[1], _p(tem), tem.shape[2], tem.shape[1], _p(out), _p(st)))
+    return out, st
+
+
+def dev_transfer(d_src, d_tem, out=None, stats=None):
+    """Device-resident colour transfer; out may be d_src itself."""
+    import torch
+    for t in (d_src, d_tem):
+        assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and t.shape[0] == 3
+    out = torch.empty_like(d_src) if out is None else out
+    _chk(lib().stitch_dev_transfer_u8(_dp(d_src), int(d_src.shape[2]), int(d_src.shape[1]), _dp(d_tem), int(d_tem.shape[2]),
+                                      int(d_tem.shape[1]), _dp(out), _dp(stats) if stats is not None else None, _stream()))
+    return out
+
+
 class BmpInfo(C.Structure):
     """stitch_bmp_info: what CImg's loader derives from the 54-byte header (CImg.h:48413-48441)."""
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bpp", C.c_int32), ("top_down", C.c_int32),

@@ -1112,6 +1112,50 @@ int stitch_dev_gray_u8(const uint8_t* d_rgb, int w, int h, uint8_t* d_gray, floa
     k_gray<<<eq_grid(n), 256, 0, as_stream(stream)>>>(d_rgb, n, d_gray, d_gray_f32);
     return launch_check("k_gray");
 }
+// ---- l-alpha-beta colour transfer ---------------------------------------------------------------------------------
+int stitch_dev_transfer_u8(const uint8_t* d_src, int sw, int sh, const uint8_t* d_tem, int tw, int th, uint8_t* d_out, float* d_stats12,
+                           void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_src || !d_tem || !d_out || sw <= 0 || sh <= 0 || tw <= 0 || th <= 0) return fail(STITCH_ERR_ARG, "transfer: null buffer or bad size");
+    if ((long long)sw * sh > 0x7fffffffLL || (long long)tw * th > 0x7fffffffLL)
+        return fail(STITCH_ERR_ARG, "transfer: w*h overflows int (the reference's int product)");
+    const size_t ns = (size_t)sw * sh, nt = (size_t)tw * th;
+    TrK k{};
+    k.a1 = (float)(1.0 / std::sqrt(3.0));
+    k.b1 = (float)(1.0 / std::sqrt(6.0));
+    k.c1 = (float)(1.0 / std::sqrt(2.0));
+    k.a2 = (float)(std::sqrt(3.0) / 3.0);
+    k.b2 = (float)(std::sqrt(6.0) / 6.0);
+    k.c2 = (float)(std::sqrt(2.0) / 2.0);
+    k.ln10 = 2.302585092994046;  // log(10)
+    hipStream_t s = as_stream(stream);
+    float* scratch = nullptr;
+    HIPCHK(hipMallocAsync((void**)&scratch, sizeof(float) * (3 * (ns + nt) + 16), s));
+    float *lab_s = scratch, *lab_t = scratch + 3 * ns, *stats = scratch + 3 * (ns + nt);
+    k_tr_to_lab<<<eq_grid(ns), 256, 0, s>>>(d_src, ns, k, lab_s);
+    k_tr_to_lab<<<eq_grid(nt), 256, 0, s>>>(d_tem, nt, k, lab_t);
+    k_tr_stats<<<6, 64, 0, s>>>(lab_s, ns, (float)(sw * sh), lab_t, nt, (float)(tw * th), stats);
+    k_tr_apply<<<eq_grid(ns), 256, 0, s>>>(lab_s, ns, stats, k, d_out);
+    if (d_stats12) HIPCHK(hipMemcpyAsync(d_stats12, stats, sizeof(float) * 12, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipFreeAsync(scratch, s));
+    return launch_check("transfer");
+}
+int stitch_transfer_u8(const uint8_t* src, int sw, int sh, const uint8_t* tem, int tw, int th, uint8_t* out, float stats_out[12]) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!src || !tem || !out || sw <= 0 || sh <= 0 || tw <= 0 || th <= 0) return fail(STITCH_ERR_ARG, "transfer: null buffer or bad size");
+    const size_t bs = (size_t)3 * sw * sh, bt = (size_t)3 * tw * th;
+    DevBuf a, b, o, st;
+    if ((rc = a.alloc(bs)) || (rc = b.alloc(bt)) || (rc = o.alloc(bs)) || (rc = st.alloc(sizeof(float) * 12))) return rc;
+    HIPCHK(hipMemcpy(a.p, src, bs, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b.p, tem, bt, hipMemcpyHostToDevice));
+    if ((rc = stitch_dev_transfer_u8(a.as<uint8_t>(), sw, sh, b.as<uint8_t>(), tw, th, o.as<uint8_t>(), st.as<float>(), nullptr))) return rc;
+    HIPCHK(hipMemcpy(out, o.p, bs, hipMemcpyDeviceToHost));
+    if (stats_out) HIPCHK(hipMemcpy(stats_out, st.p, sizeof(float) * 12, hipMemcpyDeviceToHost));
+    return STITCH_OK;
+}
+
 // ---- BMP <-> planar RGB ------------------------------------------------------------------------------------------
 static int le32(const uint8_t* p) { return (int)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 int stitch_bmp_parse(const uint8_t* f, size_t n, stitch_bmp_info* info) {

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "stitch_elem.h"
+
 #pragma clang fp contract(off)
 
 namespace sk {
@@ -190,6 +192,119 @@ __global__ __launch_bounds__(256) void k_bmp_encode(const uint8_t* __restrict__ 
     const int nbytes = (int)min((unsigned long long)BMP_SEG * 3, g.stride - seg_off);
     uint8_t* dst = file + 54 + (unsigned long long)r * g.stride + seg_off;
     for (int u = threadIdx.x; u * A < nbytes; u += 256) reinterpret_cast<U*>(dst)[u] = reinterpret_cast<const U*>(seg)[u];
+}
+
+// ---- l-alpha-beta colour transfer, transfer.cpp:3-13,125-225 (dead code in the reference) --
+// The per-pixel arithmetic with every float/double promotion where the C++ puts it; std::log(float) and
+// std::pow(10, float) are the specified functions of include/stitch_elem.h (see there).  Constants that the reference
+// obtains from sqrt() are evaluated on the host.
+struct TrK {
+    float a1, b1, c1;  // 1/sqrt(3), 1/sqrt(6), 1/sqrt(2) as float (transfer.cpp:193-195)
+    float a2, b2, c2;  // sqrt(3)/3, sqrt(6)/6, sqrt(2)/2 as float (transfer.cpp:204-206)
+    double ln10;       // log(10)
+};
+__device__ __forceinline__ void tr_rgb_to_lab(const TrK& k, float R, float G, float B, float& L, float& a, float& b) {
+    float l = (float)(0.3811 * (double)R + 0.5783 * (double)G + 0.0402 * (double)B);
+    float m = (float)(0.1967 * (double)R + 0.7244 * (double)G + 0.0782 * (double)B);
+    float s = (float)(0.0241 * (double)R + 0.1288 * (double)G + 0.8444 * (double)B);
+    if (l == 0) l = 1;
+    if (m == 0) m = 1;
+    if (s == 0) s = 1;
+    l = (float)((double)stitch_elem_logf(l) / k.ln10);
+    m = (float)((double)stitch_elem_logf(m) / k.ln10);
+    s = (float)((double)stitch_elem_logf(s) / k.ln10);
+    L = k.a1 * ((l + m) + s);
+    a = (float)((double)(k.b1 * l + k.b1 * m) - (2.0 * (double)k.b1) * (double)s);
+    b = k.c1 * l - k.c1 * m;
+}
+__device__ __forceinline__ void tr_lab_to_rgb(const TrK& k, float L, float a, float b, float& R, float& G, float& B) {
+    float l = (k.a2 * L + k.b2 * a) + k.c2 * b;
+    float m = (k.a2 * L + k.b2 * a) - k.c2 * b;
+    float s = (float)((double)(k.a2 * L) - (2.0 * (double)k.b2) * (double)a);
+    l = (float)stitch_elem_pow10((double)l);
+    m = (float)stitch_elem_pow10((double)m);
+    s = (float)stitch_elem_pow10((double)s);
+    const float r = (float)((4.4679 * (double)l - 3.5873 * (double)m) + 0.1193 * (double)s);
+    const float g = (float)(((-1.2186) * (double)l + 2.3809 * (double)m) - 0.1624 * (double)s);
+    const float bb = (float)((0.0497 * (double)l - 0.2439 * (double)m) + 1.2045 * (double)s);
+    R = r > 0.0f ? (r < 255.0f ? r : 255.0f) : 0.0f;
+    G = g > 0.0f ? (g < 255.0f ? g : 255.0f) : 0.0f;
+    B = bb > 0.0f ? (bb < 255.0f ? bb : 255.0f) : 0.0f;
+}
+__global__ __launch_bounds__(256) void k_tr_to_lab(const uint8_t* __restrict__ rgb, size_t n, TrK k, float* __restrict__ lab) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float L, a, b;
+        tr_rgb_to_lab(k, (float)rgb[i], (float)rgb[i + n], (float)rgb[i + 2 * n], L, a, b);
+        lab[i] = L;
+        lab[i + n] = a;
+        lab[i + 2 * n] = b;
+    }
+}
+// transfer.cpp:128-164: mean and standard deviation with FLOAT accumulators in raster order.  A float running sum is
+// not associative, so the order is kept: one wavefront per (image, channel) chain walks its plane serially; the 64
+// lanes only fetch (256 samples ahead, double-buffered in LDS) and square, every lane then adds the same samples in
+// the same order.  Six chains run side by side.  stats = [mean_src[3], sd_src[3], mean_tem[3], sd_tem[3]].
+__global__ __launch_bounds__(64) void k_tr_stats(const float* __restrict__ lab_s, size_t ns, float cnt_s, const float* __restrict__ lab_t,
+                                                 size_t nt, float cnt_t, float* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) float buf[2][256];
+    const int chain = blockIdx.x, c = chain % 3, lane = threadIdx.x;
+    const bool is_t = chain >= 3;
+    const size_t n = is_t ? nt : ns;
+    const float* __restrict__ p = (is_t ? lab_t : lab_s) + (size_t)c * n;
+    const float cnt = is_t ? cnt_t : cnt_s;
+    const size_t nblk = (n + 255) / 256;
+    float mean = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        // out-of-range slots add exactly nothing: 0 in the sum pass, (mean - mean)^2 = 0 in the squares pass
+        const float pad = pass ? mean : 0.f;
+        float r[4];
+        auto fetch = [&](size_t b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t i = b * 256 + (size_t)j * 64 + lane;
+                r[j] = i < n ? p[i] : pad;
+            }
+        };
+        auto stash = [&](int which) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) buf[which][j * 64 + lane] = pass ? (r[j] - mean) * (r[j] - mean) : r[j];
+        };
+        fetch(0);
+        stash(0);
+        __syncthreads();
+        float acc = 0.f;
+        for (size_t b = 0; b < nblk; ++b) {
+            if (b + 1 < nblk) fetch(b + 1);
+            const float* q = buf[b & 1];
+#pragma unroll 16
+            for (int i = 0; i < 256; ++i) acc += q[i];
+            if (b + 1 < nblk) stash((int)((b + 1) & 1));
+            __syncthreads();
+        }
+        if (pass == 0)
+            mean = acc / cnt;
+        else if (lane == 0) {
+            stats[(is_t ? 6 : 0) + c] = mean;
+            stats[(is_t ? 9 : 3) + c] = sqrtf(acc / cnt);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_tr_apply(const float* __restrict__ lab, size_t n, const float* __restrict__ stats, TrK k,
+                                                  uint8_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float st[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st[i] = stats[i];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v[3], R, G, B;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (lab[i + (size_t)c * n] - st[c]) * st[9 + c] / st[3 + c] + st[6 + c];  // transfer.cpp:168-170
+        tr_lab_to_rgb(k, v[0], v[1], v[2], R, G, B);
+        out[i] = px_store<uint8_t>(R);  // the CImg<float> -> CImg<unsigned char> assignment of transfer.cpp:12
+        out[i + n] = px_store<uint8_t>(G);
+        out[i + 2 * n] = px_store<uint8_t>(B);
+    }
 }
 
 // ---- P1: cylindrical projection, Projection.cpp:20-73 ------------------------------------------------------

@@ -217,6 +217,15 @@ int stitch_bmp_decode_u8(const uint8_t *file, size_t n, uint8_t *planar);
 int stitch_bmp_encode_u8(const uint8_t *planar, int w, int h, uint8_t *file, size_t cap);
 int stitch_dev_bmp_decode_u8(const uint8_t *d_file, size_t n, const stitch_bmp_info *info, uint8_t *d_planar, void *stream);
 int stitch_dev_bmp_encode_u8(const uint8_t *d_planar, int w, int h, uint8_t *d_file, size_t cap, void *stream);
+/* transfer::transfer (transfer.cpp:3-13, :125-225): Reinhard's l-alpha-beta colour transfer of
+ * `tem`'s statistics onto `src`.  Dead code in the reference (ImageProcess.cpp:180-182) and not buildable outside
+ * Windows, so parity is against the CPU restatement only ("parity unpinned").  The float running sums of
+ * transfer.cpp:128-164 are kept in the reference's serial order; std::log(float) / std::pow(10, float) are the
+ * specified functions of include/stitch_elem.h.  stats (optional, 12 floats): mean[3], sd[3] of the source, then of the
+ * template, in l-alpha-beta.  out may alias src. */
+int stitch_transfer_u8(const uint8_t *src, int sw, int sh, const uint8_t *tem, int tw, int th, uint8_t *out, float stats[12]);
+int stitch_dev_transfer_u8(const uint8_t *d_src, int sw, int sh, const uint8_t *d_tem, int tw, int th, uint8_t *d_out,
+                           float *d_stats12, void *stream);
 /* readFile's per-image chain in one kernel (ImageProcess.cpp:18-20): projection + gray + float staging. */
 int stitch_project_gray_u8(const uint8_t *src, int w, int h, float fov_deg, uint8_t *projected, uint8_t *gray,
                            float *gray_f32);

@@ -892,3 +892,99 @@ int oracle_bmp_encode_u8(const uint8_t *planar, int w, int h, uint8_t *file, siz
     }
     return ORACLE_OK;
 }
+
+/* ---- transfer.cpp:3-13,125-225, the l-alpha-beta colour transfer (dead code in the reference:
+ * ImageProcess.cpp:180-182 are commented out).  Restatement of the per-pixel arithmetic, which is the same in the
+ * serial branch (transfer.cpp:71-78,113-121) and in the Win32-threaded one (:15-41, rows are independent).
+ * PARITY UNPINNED: transfer.cpp does not compile here (windows.h threads) and the reference holds no output of it.
+ * The two libm calls (std::log(float), std::pow(10, float) -> pow(double,double)) are the specified functions of
+ * include/stitch_elem.h unless use_libm is set (then logf / pow of this platform's libm, for measuring the distance). */
+#include "../include/stitch_elem.h"
+static float tr_log(float v, int use_libm) { return use_libm ? logf(v) : stitch_elem_logf(v); }
+static double tr_pow10(double v, int use_libm) { return use_libm ? pow(10.0, v) : stitch_elem_pow10(v); }
+
+static void tr_rgb_to_lab(float R, float G, float B, float *L, float *a, float *b, int use_libm) { /* transfer.cpp:176-199 */
+    float l = (float)(0.3811 * (double)R + 0.5783 * (double)G + 0.0402 * (double)B);
+    float m = (float)(0.1967 * (double)R + 0.7244 * (double)G + 0.0782 * (double)B);
+    float s = (float)(0.0241 * (double)R + 0.1288 * (double)G + 0.8444 * (double)B);
+    if (l == 0) l = 1;
+    if (m == 0) m = 1;
+    if (s == 0) s = 1;
+    const double ln10 = 2.302585092994046; /* log(10): the double nearest ln 10, what any libm returns for this constant */
+    l = (float)((double)tr_log(l, use_libm) / ln10);
+    m = (float)((double)tr_log(m, use_libm) / ln10);
+    s = (float)((double)tr_log(s, use_libm) / ln10);
+    const float paraA = (float)(1.0 / sqrt(3.0)), paraB = (float)(1.0 / sqrt(6.0)), paraC = (float)(1.0 / sqrt(2.0));
+    *L = paraA * ((l + m) + s);
+    *a = (float)((double)(paraB * l + paraB * m) - (2.0 * (double)paraB) * (double)s);
+    *b = paraC * l - paraC * m;
+}
+static void tr_lab_to_rgb(float L, float a, float b, float *R, float *G, float *B, int use_libm) { /* transfer.cpp:201-225 */
+    const float paraA = (float)(sqrt(3.0) / 3.0), paraB = (float)(sqrt(6.0) / 6.0), paraC = (float)(sqrt(2.0) / 2.0);
+    float l = (paraA * L + paraB * a) + paraC * b;
+    float m = (paraA * L + paraB * a) - paraC * b;
+    float s = (float)((double)(paraA * L) - (2.0 * (double)paraB) * (double)a);
+    l = (float)tr_pow10((double)l, use_libm);
+    m = (float)tr_pow10((double)m, use_libm);
+    s = (float)tr_pow10((double)s, use_libm);
+    float r = (float)((4.4679 * (double)l - 3.5873 * (double)m) + 0.1193 * (double)s);
+    float g = (float)(((-1.2186) * (double)l + 2.3809 * (double)m) - 0.1624 * (double)s);
+    float bb = (float)((0.0497 * (double)l - 0.2439 * (double)m) + 1.2045 * (double)s);
+    *R = r > 0.0f ? (r < 255.0f ? r : 255.0f) : 0.0f;
+    *G = g > 0.0f ? (g < 255.0f ? g : 255.0f) : 0.0f;
+    *B = bb > 0.0f ? (bb < 255.0f ? bb : 255.0f) : 0.0f;
+}
+static float *tr_lab_image(const uint8_t *rgb, int w, int h, int use_libm) { /* transfer.cpp:4-9, :83-123 */
+    const size_t n = (size_t)w * h;
+    float *lab = (float *)malloc(sizeof(float) * 3 * n);
+    if (!lab) return NULL;
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i)
+        tr_rgb_to_lab((float)rgb[i], (float)rgb[n + i], (float)rgb[2 * n + i], &lab[i], &lab[n + i], &lab[2 * n + i], use_libm);
+    return lab;
+}
+/* mean and standard deviation exactly as transfer.cpp:128-164: float accumulators, raster order, serial */
+static void tr_stats(const float *lab, size_t n, int w, int h, float mean[3], float sd[3]) {
+    for (int c = 0; c < 3; ++c) {
+        const float *p = lab + (size_t)c * n;
+        float acc = 0;
+        for (size_t i = 0; i < n; ++i) acc += p[i];
+        mean[c] = acc / (float)(w * h);
+        float var = 0;
+        for (size_t i = 0; i < n; ++i) var += (p[i] - mean[c]) * (p[i] - mean[c]);
+        sd[c] = sqrtf(var / (float)(w * h));
+    }
+}
+int oracle_transfer_u8(const uint8_t *src, int sw, int sh, const uint8_t *tem, int tw, int th, uint8_t *out, float stats[12],
+                       int use_libm) {
+    if (!src || !tem || !out || sw <= 0 || sh <= 0 || tw <= 0 || th <= 0) return ORACLE_ERR_ARG;
+    const size_t n = (size_t)sw * sh, nt = (size_t)tw * th;
+    float *ls = tr_lab_image(src, sw, sh, use_libm), *lt = tr_lab_image(tem, tw, th, use_libm);
+    if (!ls || !lt) {
+        free(ls);
+        free(lt);
+        return ORACLE_ERR_ARG;
+    }
+    float ms[3], ss[3], mt[3], st[3];
+    tr_stats(ls, n, sw, sh, ms, ss);
+    tr_stats(lt, nt, tw, th, mt, st);
+    if (stats)
+        for (int c = 0; c < 3; ++c) {
+            stats[c] = ms[c];
+            stats[3 + c] = ss[c];
+            stats[6 + c] = mt[c];
+            stats[9 + c] = st[c];
+        }
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) { /* transfer.cpp:165-171, then :43-81, then the cast of :12 */
+        float v[3], R, G, B;
+        for (int c = 0; c < 3; ++c) v[c] = (ls[(size_t)c * n + i] - ms[c]) * st[c] / ss[c] + mt[c];
+        tr_lab_to_rgb(v[0], v[1], v[2], &R, &G, &B, use_libm);
+        out[i] = (uint8_t)R;
+        out[n + i] = (uint8_t)G;
+        out[2 * n + i] = (uint8_t)B;
+    }
+    free(ls);
+    free(lt);
+    return ORACLE_OK;
+}

@@ -106,6 +106,12 @@ int oracle_bmp_parse(const uint8_t *file, size_t n, oracle_bmp_info *info);
 int oracle_bmp_decode_u8(const uint8_t *file, size_t n, uint8_t *planar);
 size_t oracle_bmp_file_bytes(int w, int h);
 int oracle_bmp_encode_u8(const uint8_t *planar, int w, int h, uint8_t *file, size_t cap);
+/* transfer.cpp:3-13,125-225 (l-alpha-beta colour transfer; dead code in the reference).
+ * PARITY UNPINNED (transfer.cpp needs windows.h; no output of it exists in the reference).  stats (optional) receives
+ * mean[3], sd[3] of the source and mean[3], sd[3] of the template in l-alpha-beta.  use_libm = 0: the specified
+ * log / pow10 of include/stitch_elem.h (what the product computes); 1: this platform's logf / pow. */
+int oracle_transfer_u8(const uint8_t *src, int sw, int sh, const uint8_t *tem, int tw, int th, uint8_t *out, float stats[12],
+                       int use_libm);
 /* synthetic frame generator of SURVEY.md 8(d) */
 void oracle_synth_u8(uint8_t *dst, int w, int h, int frame_id);
 void oracle_synth_f32(float *dst, int w, int h, int frame_id);

@@ -58,6 +58,12 @@ for (w, h, tag) in ((F, F, "frame 4096x4096"), (cw, ch, "mosaic 6144x4096")):
     ms = timeit(lambda: capi.dev_bmp_decode(fil, bi, back))
     res[f"bmp_decode_u8 {tag}"] = {"ms": ms, "MPix/s": w * h / ms / 1e3, "GB/s (file + planar bytes)": (fil.numel() + img.numel()) / ms / 1e6}
     assert torch.equal(back, img)
+# l-alpha-beta colour transfer: dominated by the serial float running sums the reference prescribes
+for (w, h) in ((384, 512), (F, F)):
+    a, b = capi.dev_synth(w, h, 1, torch.uint8, dev), capi.dev_synth(w, h, 8, torch.uint8, dev)
+    o = torch.empty_like(a)
+    ms = timeit(lambda: capi.dev_transfer(a, b, out=o), reps=5)
+    res[f"transfer_u8 {w}x{h} (template of the same size)"] = {"ms": ms, "MPix/s": w * h / ms / 1e3}
 # host-pointer pair (PCIe inclusive)
 import numpy as np, time
 A = capi.dev_synth(F, F, 0, torch.float32, dev).cpu().numpy()

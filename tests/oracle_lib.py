@@ -250,6 +250,16 @@ class Oracle:
         getattr(self.lib, "oracle_synth_" + ("u8" if dtype == np.uint8 else "f32"))(_p(out), w, h, int(frame_id))
         return out
 
+    def transfer(self, src, tem, use_libm=False):
+        """-> (out, stats[12]); use_libm: this platform's logf/pow instead of include/stitch_elem.h"""
+        src, tem = _img(src, np.uint8), _img(tem, np.uint8)
+        out, st = np.empty_like(src), np.zeros(12, np.float32)
+        self.lib.oracle_transfer_u8.restype = C.c_int
+        rc = self.lib.oracle_transfer_u8(_p(src), src.shape[2], src.shape[1], _p(tem), tem.shape[2], tem.shape[1], _p(out), _p(st),
+                                         int(use_libm))
+        assert rc == 0, rc
+        return out, st
+
     def bmp_decode(self, data):
         """bytes of a BMP file -> (rc, planar (3,H,W) uint8 or None)"""
         buf = np.frombuffer(bytes(data), np.uint8)

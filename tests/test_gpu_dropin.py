@@ -50,3 +50,28 @@ def test_reference_control_flow_on_hip_kernels(n):
     # project and gray once per frame, warp/move/blend once per stitched neighbour, equalise once
     assert r["calls"] == [n, n - 1, n - 1, n - 1, 1, n], r["calls"]
     assert r["sha256"] == run["final_sha256"], (r["mean"], run["final_mean"])
+
+
+TRANSFER_SCRIPT = r'''
+import ctypes as C, hashlib, json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[2])
+import oracle_lib
+dropin = C.CDLL(sys.argv[1], mode=C.RTLD_GLOBAL)
+O = oracle_lib.Oracle()
+src, tem = O.synth(300, 200, 1), O.synth(97, 61, 8)
+want, _ = O.transfer(src, tem)
+got = src.copy()
+rc = dropin.stitch_dropin_transfer_in_place(got.ctypes.data_as(C.c_void_p), 300, 200, tem.ctypes.data_as(C.c_void_p), 97, 61)
+print("RESULT " + json.dumps({"rc": rc, "equal": bool(np.array_equal(got, want)), "calls": dropin.stitch_dropin_call_count(6)}))
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in artefacts are built only where /root/reference exists (make -C oracle ref)")
+def test_transfer_class_binding():
+    """The reference's `transfer` class (transfer.h; its own transfer.cpp needs the Win32 thread API) constructed exactly
+    as ImageProcess.cpp:180 would -- output aliasing the source -- runs on the HIP path and equals the CPU restatement."""
+    out = subprocess.run([sys.executable, "-c", TRANSFER_SCRIPT, DROPIN, HERE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert r == {"rc": 0, "equal": True, "calls": 1}, r

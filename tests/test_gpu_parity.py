@@ -320,3 +320,38 @@ def test_bmp_refusals(st, gpu):
         assert e.value.code == st.capi.ERR_ARG
     with pytest.raises(st.StitchError):
         capi.bmp_decode(bytes(good[:40]))
+
+
+@pytest.mark.parametrize("sw,sh,tw,th", [(384, 512, 384, 512), (300, 200, 97, 61), (257, 129, 640, 360), (16, 16, 5, 3), (1, 1, 2, 2), (1000, 1000, 333, 77)])
+def test_colour_transfer(st, gpu, oracle, sw, sh, tw, th):
+    """SURVEY.md 8(f) row 4 (transfer.cpp; parity unpinned, see include/stitch.h): the HIP path equals the CPU
+    restatement bit for bit -- the uchar result AND the twelve float statistics, whose serial float running sums are the
+    order-sensitive part (sizes that are not multiples of the 256-sample staging block included)."""
+    import torch
+    from computervisionimagestich2_amd import capi
+    src, tem = oracle.synth(sw, sh, 1), oracle.synth(tw, th, 8)
+    tem[0] //= 2  # a template with a different colour balance
+    ref, rst = oracle.transfer(src, tem)
+    got, gst = capi.transfer(src, tem)
+    assert np.array_equal(gst.view(np.uint32), rst.view(np.uint32)), (gst, rst)
+    assert np.array_equal(got, ref)
+    # device-resident, in place
+    d = torch.from_numpy(src).to(gpu)
+    capi.dev_transfer(d, torch.from_numpy(tem).to(gpu), out=d)
+    assert np.array_equal(d.cpu().numpy(), ref)
+
+
+def test_colour_transfer_degenerate(st, gpu, oracle):
+    """A constant source channel has standard deviation 0: the reference divides by it (transfer.cpp:168-170); the
+    clamps of LabToRGB map the NaN/inf that follows to 0/255.  Same bytes on both sides."""
+    from computervisionimagestich2_amd import capi
+    src = np.full((3, 40, 30), 77, np.uint8)
+    tem = oracle.synth(64, 48, 3)
+    ref, _ = oracle.transfer(src, tem)
+    got, _ = capi.transfer(src, tem)
+    assert np.array_equal(got, ref)
+    src = oracle.synth(30, 40, 2)
+    src[:, :3, :] = 0  # black pixels: l = m = s = 0 is replaced by 1 (transfer.cpp:184-186)
+    ref, rst = oracle.transfer(src, tem)
+    got, gst = capi.transfer(src, tem)
+    assert np.array_equal(got, ref) and np.array_equal(gst.view(np.uint32), rst.view(np.uint32))
