@@ -5,10 +5,12 @@ A step = one pass of the hot path (warp + move + multi-band blend) over syntheti
 batches of --batch (default 3) independent config-2 pairs per rank (two 4096x4096x3 f32 frames -> 6144x4096x3 f32
 mosaic each; pair i of the config-4 family has p[3] = -2048 - 8i); a batch is ONE launch sequence of a batched plan
 on its own HIP stream.  Frames are generated on the device before the timed
-region, so every input is resident in HBM when timing starts.  Pairs are independent: no data-path collective;
-for N>1 each finished mosaic is cast to unsigned char (the reference's own output type) and all-gathered
-(RCCL over xGMI) on the communicator's stream while the next pair computes, so that every rank ends up holding
-the whole batch -- that exchange is inside the timed region.
+region, so every input is resident in HBM when timing starts.  Pairs are independent: each rank works on its own
+shard and there is NO data-path collective (weak scaling; RCCL carries only the barriers and the max-over-ranks of
+the step time).  --gather adds the optional assembly of SURVEY.md 8(e): each finished mosaic is cast to unsigned char
+(the reference's own output type) and all-gathered (RCCL over xGMI) on the communicator's stream while the next
+batch computes, so that every rank ends up holding the whole batch -- that exchange is then inside the timed region
+(at 8 GPUs it moves 5.4 GB per step into every rank and is link-bound, which is why it is not the default).
 
 Prints ONE JSON line (rank 0).  `value` comes from timed region 1 (all batches in flight).  `roofline` describes
 the dominant kernel (largest share of device time) in timed region 2, where one batch is in flight so that a
@@ -40,6 +42,7 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="time without per-launch HIP events")
     ap.add_argument("--pixel", choices=["f32", "u8"], default="f32", help="frame pixel type (f32 = the metric; u8 = the reference's own contract)")
     ap.add_argument("--no-single", action="store_true", help="skip the single-pair-in-flight latency measurement")
+    ap.add_argument("--gather", action="store_true", help="N>1: all-gather the finished uchar mosaics to every rank each step (inside the timed region)")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -111,6 +114,7 @@ def main():
     # a rehearsal of the multi-GPU path on a one-GPU box; it is never set by the driver
     force_dist = world == 1 and os.environ.get("STITCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
+    use_gather = force_dist or (world > 1 and args.gather)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with _StdoutToStderr():
@@ -152,7 +156,7 @@ def main():
             "outs": [[torch.empty((3, ch, cw), dtype=tdt, device=dev) for _ in range(B)] for _ in range(2)],
             # N>1: finished mosaics travel as unsigned char (the reference's output type) through pipeline.MosaicGather
             # -- the class the gloo tests cover -- asynchronously: the gather of step k overlaps the kernels of step k+1
-            "gather": pipeline.MosaicGather((B, 3, ch, cw), dev, world, rank, slots=2, force_collective=force_dist) if use_dist else None,
+            "gather": pipeline.MosaicGather((B, 3, ch, cw), dev, world, rank, slots=2, force_collective=force_dist) if use_gather else None,
         })
     plan = lanes[0]["plan"]
 
@@ -263,7 +267,7 @@ def main():
                        "single_pair_in_flight_ms": round(single_ms, 4) if single_ms else None,
                        "single_pair_in_flight_mpix_s": round(mpix_pair / single_ms * 1e3, 1) if single_ms else None,
                        "input_frame_mpix_per_s": round(2 * F * F / 1e6 * K * B * S * world / elapsed, 2),
-                       "exchange": "none" if world == 1 else "uint8 mosaics all-gathered (RCCL) overlapped with compute",
+                       "exchange": "uint8 mosaics all-gathered (RCCL) overlapped with compute" if use_gather else "none (independent shards; RCCL for barriers and timing only)",
                        "seam": list(seam.as_tuple())},
         }
         if prof[dom][1] > 0:
@@ -298,7 +302,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_frame, args.verbose)
         print(json.dumps(line), flush=True)
-    if use_dist and rank == 0 and os.environ.get("STITCH_CHECK_GATHER") == "1":
+    if use_gather and rank == 0 and os.environ.get("STITCH_CHECK_GATHER") == "1":
         # rehearsal check: the last gathered block of lane 0 holds this rank's own quantised mosaics
         L = lanes[0]
         last = W + PILOT + 2 * K - 1
