@@ -276,9 +276,28 @@ __global__ __launch_bounds__(64) void k_tr_stats(const float* __restrict__ lab_s
         float acc = 0.f;
         for (size_t b = 0; b < nblk; ++b) {
             if (b + 1 < nblk) fetch(b + 1);
-            const float* q = buf[b & 1];
-#pragma unroll 16
-            for (int i = 0; i < 256; ++i) acc += q[i];
+            // the add chain is the critical path (one dependent v_add_f32 per sample): LDS reads run one 16-sample
+            // group ahead of it, in registers
+            const f4* q = reinterpret_cast<const f4*>(buf[b & 1]);
+            f4 cur[4], nxt[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = q[j];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                if (g + 1 < 16) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nxt[j] = q[4 * (g + 1) + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc += cur[j].x;
+                    acc += cur[j].y;
+                    acc += cur[j].z;
+                    acc += cur[j].w;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+            }
             if (b + 1 < nblk) stash((int)((b + 1) & 1));
             __syncthreads();
         }
