@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
     while (!dead) {
         unsigned q = 0;
         if (lane == 0) q = atomicAdd(wf.counter, 1u);
-        q = __shfl(q, 0, 64);
+        q = __builtin_amdgcn_readfirstlane(__shfl(q, 0, 64));  // provably wave-uniform: band, plane and every branch on them stay scalar
         if (q >= nbands) break;
         const int R = (int)(q / wf.NP), p = (int)(q % wf.NP);  // every plane's band R before any band R+1
         const int r0 = R * TS, nrows = min(TS, h - r0);
@@ -1527,17 +1527,30 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             const double iplus_y = const_rows ? (double)rowv : (double)colp[(nrows - 1) * TP];  // last band only (CImg.h:34906)
             for (int j0 = 0; j0 < nrows; j0 += 16) {
                 if (j0 + 16 <= nrows) {
+                    // all 16 column samples are read before the chain starts and written after it ends: a read placed
+                    // between the writes would be kept in program order (the compiler cannot tell the rows apart) and
+                    // put one LDS round trip per sample on the critical path
+                    float ys[16];
+                    if (const_rows) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) ys[u] = rowv;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) ys[u] = colp[(j0 + u) * TP];
+                    }
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
-                        double v0 = const_rows ? (double)rowv : (double)colp[(j0 + u) * TP];
+                        double v0 = (double)ys[u];
                         v0 += u1 * k.f1;
                         v0 += u2 * k.f2;
                         v0 += u3 * k.f3;
-                        colp[(j0 + u) * TP] = (float)v0;
+                        ys[u] = (float)v0;
                         u3 = u2;
                         u2 = u1;
                         u1 = v0;
                     }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) colp[(j0 + u) * TP] = ys[u];
                 } else {
                     for (int j = j0; j < nrows; ++j) {
                         double v0 = const_rows ? (double)rowv : (double)colp[j * TP];
