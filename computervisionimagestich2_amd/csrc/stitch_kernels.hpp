@@ -1248,7 +1248,9 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
                                                       VVK k, const double* __restrict__ state, float* __restrict__ dst,
                                                       int w2, int h2, int dpitch, size_t dps) {
     __shared__ __attribute__((aligned(16))) float ring[2][YCH][YCOLS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave id is wave-uniform, but anything derived from threadIdx is a lane value to the compiler: readfirstlane
+    // keeps the producer/consumer role branches scalar
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nchunks = (h + YCH - 1) / YCH;
     const int x = (blockIdx.x * WAVE + lane) * 2;  // first of this lane's two columns
     const bool col_live = x < pitch;
