@@ -192,6 +192,8 @@ struct stitch_plan {
     u64* wf_yg = nullptr;
     size_t wf_yg_bytes = 0;
     unsigned* wf_ctrl = nullptr;   // per level one band-queue head (16 words apart), then the abort flag
+    uint8_t* zt = nullptr;         // zero-tile flags of T, [7*cap][bands][tiles] of level 0 (ZeroTiles); reused level by level
+    bool zero_tiles = false;
     unsigned long long* wf_dbg = nullptr;  // STITCH_WAVEFRONT_STAMP=1: [2048][8] segment cycle sums (diagnostics)
     unsigned* h_wf_abort = nullptr;  // pinned copy of the abort flag of the last call
     float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
@@ -269,14 +271,22 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             mk.enabled = 1;
         }
         const bool wavefront = p->opts.blur_kind == 0 && do_x && do_y && l < p->wf_levels;
+        // zero-tile flags: only where all three users run (causal x sweep, fused sweep, fused anticausal-y + decimation)
+        ZeroTiles zt{};
+        if (wavefront && p->zero_tiles && (a.h % TS) == 0 && a.h / TS <= 256 && (a.w & 1) == 0 && !p->no_fuse) {
+            zt.flags = p->zt;
+            zt.h = a.h;
+            zt.NR = a.h / TS;
+            zt.NC = (a.w + TS - 1) / TS;
+        }
         if (wavefront) {
             const int nb = (int)((lines + TS - 1) / TS);
             {
                 StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
                 if (src && l == 0)
-                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa);
+                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt);
                 else
-                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{});
+                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt);
             }
             Wavefront wf{};
             wf.yg = p->wf_yg;
@@ -291,6 +301,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             k_clear_words<<<(int)std::min<size_t>((gran_words + 255) / 256, 2048), 256, 0, s>>>(p->wf_yg, gran_words);
             wf.epoch = 1;
             wf.mask_l0 = mk.enabled;
+            wf.zt = zt;
             const long ntiles = (long)wf.NP * wf.NR;  // one persistent wavefront per row band
             // the x-sweep state lives in state[0 .. 4*lines); the y state the kernel leaves goes behind it
             double* state_y = p->state + 4 * (size_t)p->cap * 7 * (a.h + 64);
@@ -306,7 +317,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
             dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
             if ((a.w & 1) == 0 && !p->no_fuse) {
-                k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps);
+                k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, zt);
                 decimated = true;
             } else
                 k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, state_y);
@@ -316,9 +327,9 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
                     if (src && l == 0)
-                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa);
+                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt);
                 else
-                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{});
+                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt);
                 }
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
@@ -334,7 +345,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 }
                 StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
                 if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
-                    k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
+                    k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{});
                     decimated = true;
                 } else
                     k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
@@ -887,6 +898,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     const int NC0 = (v0.w + TS - 1) / TS;
     const size_t yg_off = wf_levels ? take(sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE) : 0;
     const size_t wfc_off = wf_levels ? take(sizeof(unsigned) * WF_CTRL_WORDS) : 0;
+    const size_t zt_off = wf_levels ? take((size_t)7 * B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS)) : 0;
     // x-sweep state [4][lines] followed by the y state the wavefront kernel leaves [4][planes][pitch]
     const size_t state_n = 4 * 7 * B * (size_t)(v0.h + 64) + 4 * 7 * B * (size_t)std::max(v0.h + 64, v0.pitch);
     const size_t st_off = take(sizeof(double) * state_n);
@@ -922,6 +934,9 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         p->wf_yg = reinterpret_cast<u64*>(base + yg_off);
         p->wf_yg_bytes = sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE;
         p->wf_ctrl = reinterpret_cast<unsigned*>(base + wfc_off);
+        p->zt = reinterpret_cast<uint8_t*>(base + zt_off);
+        const char* ez = std::getenv("STITCH_NO_ZERO_TILES");  // A/B and tests: move the zeros like any other sample
+        p->zero_tiles = !(ez && atoi(ez) != 0);
     }
     p->side = reinterpret_cast<float*>(base + side_off);
     // implicit level-0 mask: needs both Van Vliet sweeps at level 0 and 64-row blocks that do not straddle planes

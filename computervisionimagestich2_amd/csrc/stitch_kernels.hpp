@@ -764,6 +764,19 @@ __device__ __forceinline__ void tile_store(float* __restrict__ base, int pitch, 
         *reinterpret_cast<f4*>(p + (size_t)(4 * i) * pitch) = *reinterpret_cast<const f4*>(t + (4 * i) * TP);
 }
 
+// Sparse canvases.  A stitched canvas is mostly empty for either image (the reference blurs and decimates the zeros
+// like everything else), and the recursive filters leave exact +0.0f wherever the input was zero and the state has
+// died out (about 150 samples past the data; the tails of these images are non-negative).  For the levels the fused
+// sweep covers (heights that are multiples of 64), a kernel that produces a 64x64 tile of the blur scratch T made of
+// +0.0f only records one byte instead of storing the tile, and the next kernel takes the zeros from the flag instead
+// of from HBM.  The arithmetic is unchanged (zeros are swept like any other sample); only stores and loads of
+// zeros are skipped.  The test is on the bit pattern, so a -0.0f keeps its tile "non-zero".
+struct ZeroTiles {
+    uint8_t* flags;  // [planes][NC][NR] (bands of one tile column are contiguous), nullptr = feature off for this level
+    int h, NR, NC;   // rows per plane, 64-row bands per plane, 64-column tiles per row
+    __device__ __forceinline__ size_t index(long plane, int band, int tile) const { return ((size_t)plane * NC + tile) * NR + band; }
+};
+
 // Level-0 mask without a level-0 mask plane.  The reference's mask[0] is a vertical step (ImageProcess.cpp:690-698):
 // every row is the same function of x, so (when the level height is a multiple of 64, i.e. a 64-row block never
 // straddles planes) the x sweeps generate the step on the fly, compute only the first 64 of its identical rows,
@@ -846,7 +859,7 @@ __device__ __forceinline__ void src_finish(bool warped, f4 pre[16]) {  // raw bi
 template <typename PX, bool SRC>
 __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, float* __restrict__ out, int w, int pitch,
                                                   long lines, VVK k, double* __restrict__ state, MaskL0 mk,
-                                                  typename CollapseSrc<PX, SRC>::type pa) {
+                                                  typename CollapseSrc<PX, SRC>::type pa, ZeroTiles zt) {
     __shared__ __attribute__((aligned(16))) float tile[TS * TP];
     const int lane = threadIdx.x;
     const long line0 = (long)blockIdx.x * TS, line = line0 + lane;
@@ -927,6 +940,7 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
         const int jmax = min(TS, w - t * TS);
         if (t == 0) v1 = v2 = v3 = (double)row[0] / k.sumsq;  // CImg.h:34909
         const int jfull = jmax & ~15;
+        unsigned nz = 0;  // OR of the bit patterns this lane stores: 0 <=> every sample is +0.0f
         for (int jb = 0; jb < jfull; jb += 16) {
             float xs[16];
 #pragma unroll
@@ -938,6 +952,7 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
                 v0 += v2 * k.f2;
                 v0 += v3 * k.f3;
                 xs[u] = (float)v0;
+                nz |= __float_as_uint(xs[u]);
                 v3 = v2;
                 v2 = v1;
                 v1 = v0;
@@ -951,11 +966,17 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
             v0 += v2 * k.f2;
             v0 += v3 * k.f3;
             row[j] = (float)v0;
+            nz |= __float_as_uint(row[j]);
             v3 = v2;
             v2 = v1;
             v1 = v0;
         }
         __syncthreads();
+        if (zt.flags) {  // an all-(+0) tile is recorded instead of written: its consumers never read it (ZeroTiles)
+            const bool zero = __ballot(nz != 0) == 0;
+            if (lane == 0) zt.flags[zt.index(line0 / zt.h, (int)((line0 % zt.h) / TS), t)] = zero ? 1 : 0;
+            if (zero) continue;
+        }
         tile_store(ob, pitch, t * TS, lane, tile);
     }
     if (live) {
@@ -1246,7 +1267,7 @@ __global__ __launch_bounds__(64) void k_vv_y_bwd(float* __restrict__ data, int h
 // One workgroup barrier per YCH rows hands a slot over.  rc = h-1-y counts rows in processing order.
 __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ data, int w, int h, int pitch, size_t ps,
                                                       VVK k, const double* __restrict__ state, float* __restrict__ dst,
-                                                      int w2, int h2, int dpitch, size_t dps) {
+                                                      int w2, int h2, int dpitch, size_t dps, ZeroTiles zt) {
     __shared__ __attribute__((aligned(16))) float ring[2][YCH][YCOLS];
     // the wave id is wave-uniform, but anything derived from threadIdx is a lane value to the compiler: readfirstlane
     // keeps the producer/consumer role branches scalar
@@ -1258,16 +1279,46 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
     Y2 s{};
     f2 first{};
     f2 buf[YST][YCH];
-    auto ld = [&](int rc) {
-        const int r = rc < h ? rc : h - 1;
-        return *reinterpret_cast<const f2*>(p + (size_t)(h - 1 - r) * pitch);
+    // zero-tile flags of this lane's 64-column tile, one bit per 64-row band, gathered once before the walk starts (the
+    // host enables the flags only up to 256 bands); the row loop then only tests a bit
+    unsigned long long zm[4] = {0, 0, 0, 0};
+    const bool zt_on = zt.flags != nullptr;
+    if (zt_on) {
+        const uint8_t* ztcol = zt.flags + zt.index(blockIdx.y, 0, (col_live ? x : 0) >> 6);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g * 64 < zt.NR) {  // wave-uniform
+                unsigned char fb[64];
+#pragma unroll
+                for (int i = 0; i < 64; ++i) fb[i] = g * 64 + i < zt.NR ? ztcol[g * 64 + i] : 0;
+#pragma unroll
+                for (int i = 0; i < 64; ++i) zm[g] |= (unsigned long long)(fb[i] != 0) << i;
+            }
+        }
+    }
+    // A chunk of YCH rows never straddles a 64-row band (heights with flags are multiples of 64), so the flag is looked up
+    // once per chunk.  The loads stay branch-free (the prefetch stream must remain one straight run of loads): a lane whose
+    // tile is flagged re-reads one fixed row of its column -- a cache hit after the first time, no HBM traffic -- and
+    // discards it.
+    auto chunk_zero = [&](int chunk) {
+        if (!zt_on) return false;
+        const int rc = chunk * YCH, r = rc < h ? rc : h - 1, b = (h - 1 - r) >> 6, g = b >> 6;
+        const unsigned long long m = g == 0 ? zm[0] : g == 1 ? zm[1] : g == 2 ? zm[2] : zm[3];
+        return ((m >> (b & 63)) & 1) != 0;
+    };
+    auto ld = [&](int rc, bool zero) {
+        const int r = rc < h ? rc : h - 1, y = h - 1 - r;
+        const f2 v = *reinterpret_cast<const f2*>(p + (size_t)(zero ? h - 1 : y) * pitch);
+        return zero ? f2{0.f, 0.f} : v;
     };
     if (wave == 0) {
         if (col_live) y2_triggs(k, state, (size_t)gridDim.y * pitch, ystate_index(blockIdx.y, pitch, x), s, first);
 #pragma unroll
-        for (int st = 0; st < YST - 1; ++st)
+        for (int st = 0; st < YST - 1; ++st) {
+            const bool z = chunk_zero(st);
 #pragma unroll
-            for (int u = 0; u < YCH; ++u) buf[st][u] = ld(st * YCH + u);
+            for (int u = 0; u < YCH; ++u) buf[st][u] = ld(st * YCH + u, z);
+        }
     }
     // consumer state: this lane's output column t_x = x/2
     const float fsx = (float)(unsigned)w2, fw = (float)(unsigned)w, fh = (float)(unsigned)h, fsy = (float)(unsigned)h2;
@@ -1282,8 +1333,9 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
         for (int st = 0; st < YST; ++st) {
             const int j = j0 + st;
             if (wave == 0) {
+                const bool z = chunk_zero(j + YST - 1);
 #pragma unroll
-                for (int u = 0; u < YCH; ++u) buf[(st + YST - 1) % YST][u] = ld((j + YST - 1) * YCH + u);
+                for (int u = 0; u < YCH; ++u) buf[(st + YST - 1) % YST][u] = ld((j + YST - 1) * YCH + u, z);
                 if (j < nchunks) {
 #pragma unroll
                     for (int u = 0; u < YCH; ++u) {
@@ -1350,6 +1402,7 @@ struct Wavefront {
     unsigned* abort;    // set when a spin timed out
     int NR, NC, NP;
     unsigned epoch;
+    ZeroTiles zt;             // zero-tile flags of T at this level (see ZeroTiles)
     unsigned long long* dbg;  // diagnostic build only: [workgroups][8] cycle sums per segment
 };
 
@@ -1461,17 +1514,33 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             triggs(k, iplus, v1, v2, v3, first);
         }
         f4 pre[16];
-        if (!const_rows) tile_load(base, pitch, (wf.NC - 1) * TS, lane, pre);
+        // tile C of this band into `pre`: from HBM, or zeros when the causal x sweep recorded it as all +0
+        auto fetch_tile = [&](int C) {  // true: the tile is all +0
+            if (wf.zt.flags && wf.zt.flags[wf.zt.index(p, R, C)]) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pre[i] = f4{0.f, 0.f, 0.f, 0.f};
+                return true;
+            }
+            tile_load(base, pitch, C * TS, lane, pre);
+            return false;
+        };
+        bool next_zero = false;
+        if (!const_rows) next_zero = fetch_tile(wf.NC - 1);
         for (int C = wf.NC - 1; C >= 0; --C) {
             const int c0 = C * TS, ncols = min(TS, w - c0);
+            const bool tile_zero = next_zero;  // the tile now going to LDS holds +0 only
             if (!const_rows) {
                 tile_to_lds(tile, lane, pre);
-                if (C > 0) tile_load(base, pitch, c0 - TS, lane, pre);  // next tile of the band, in flight during both sweeps
+                if (C > 0) next_zero = fetch_tile(C - 1);  // next tile of the band, in flight during both sweeps
             }
             __syncthreads();
             stamp(1);  // tile fetch
             // ---- anticausal x sweep, lane = row r0+lane ---------------------------------------------------------
-            if (!const_rows) {
+            // Zeros in, zero state: every product and sum of the recurrence is +0 again (x*sum = +0, and +0 plus a zero of
+            // either sign is +0), so the sweep would rewrite the zeros it found and leave the state as it is: skipped.
+            const bool x_idle = tile_zero && !const_rows && C != wf.NC - 1 &&
+                                __ballot((__double_as_longlong(v1) | __double_as_longlong(v2) | __double_as_longlong(v3)) != 0) == 0;
+            if (!const_rows && !x_idle) {
                 float* row = tile + lane * TP;
                 int jtop = ncols;
                 if (C == wf.NC - 1) {
@@ -1526,8 +1595,12 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             }
             stamp(3);  // y state wait
             const float rowv = __uint_as_float(rowbits);
+            unsigned ynz = 0;  // OR of the bit patterns of this lane's column after the sweep
             const double iplus_y = const_rows ? (double)rowv : (double)colp[(nrows - 1) * TP];  // last band only (CImg.h:34906)
-            for (int j0 = 0; j0 < nrows; j0 += 16) {
+            // the same for the y sweep: a tile of +0 under a +0 state stays +0 (only the columns that exist are asked)
+            const bool y_idle = x_idle && __ballot(lane < ncols && (__double_as_longlong(u1) | __double_as_longlong(u2) |
+                                                                   __double_as_longlong(u3)) != 0) == 0;
+            for (int j0 = 0; j0 < (y_idle ? 0 : nrows); j0 += 16) {
                 if (j0 + 16 <= nrows) {
                     // all 16 column samples are read before the chain starts and written after it ends: a read placed
                     // between the writes would be kept in program order (the compiler cannot tell the rows apart) and
@@ -1547,6 +1620,7 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
                         v0 += u2 * k.f2;
                         v0 += u3 * k.f3;
                         ys[u] = (float)v0;
+                        ynz |= __float_as_uint(ys[u]);
                         u3 = u2;
                         u2 = u1;
                         u1 = v0;
@@ -1560,6 +1634,7 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
                         v0 += u2 * k.f2;
                         v0 += u3 * k.f3;
                         colp[j * TP] = (float)v0;
+                        ynz |= __float_as_uint(colp[j * TP]);
                         u3 = u2;
                         u2 = u1;
                         u1 = v0;
@@ -1577,7 +1652,12 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             }
             __syncthreads();
             stamp(4);  // y sweep + publish
-            tile_store_rows(base, pitch, c0, lane, tile, nrows);  // a partial last band must not touch the next plane's rows
+            bool out_zero = false;
+            if (wf.zt.flags) {  // the y sweep ran over every column of the tile; columns >= w hold whatever the fetch left: not counted
+                out_zero = __ballot(lane < ncols && ynz != 0) == 0;
+                if (lane == 0) wf.zt.flags[wf.zt.index(p, R, C)] = out_zero ? 1 : 0;
+            }
+            if (!out_zero) tile_store_rows(base, pitch, c0, lane, tile, nrows);  // a partial last band must not touch the next plane's rows
             __syncthreads();  // the tile buffer is refilled next
             stamp(5);  // store
         }
