@@ -3,9 +3,10 @@
 
 HBM bytes per kernel = 2*FETCH_SIZE + WRITE_SIZE, both counters in KiB.  The factor 2 on FETCH_SIZE is the gfx950
 correction of /opt/skills/guides/MI355X_MICROARCH.md ("FETCH_SIZE reports exactly half of the bytes of a wide
-coalesced streaming read"); it is checked here against a kernel whose bytes are known exactly: the level-1 launch of
-k_vv_x_fwd<float, false> streams n_pairs*7 planes of 3072 x 2048 floats in and the same out, so 2*FETCH_SIZE and
-WRITE_SIZE (which needs no correction) must both come out at 7*n_pairs*3072*2048*4 bytes -- the calibration entry.  Counters come from separate passes (FETCH_SIZE and
+coalesced streaming read"); it is checked here against a kernel whose bytes are known exactly: the level-2 launch of
+k_vv_x_bwd sweeps n_pairs*7 planes of 1536 x 1024 floats in place, so 2*FETCH_SIZE and WRITE_SIZE (which needs no
+correction) must both come out at 7*n_pairs*1536*1024*4 bytes -- the calibration entry.  (Levels 0 and 1 no longer
+qualify: their all-zero tiles are neither stored nor read.)  Counters come from separate passes (FETCH_SIZE and
 WRITE_SIZE do not fit one pass)."""
 import collections
 import csv
@@ -77,9 +78,8 @@ for g, e in out.items():
     e["hbm_bytes_per_launch"] = int(hbm / n) if n else None
     e["batch"] = batch
 out["_meta"] = {"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, averaged over the run's steps",
-                "calibration_k_vv_x_fwd_level1": {"FETCH_SIZE_KiB_max": fmax.get("k_vv_x_fwd<float, false>"),
-                                                  "WRITE_SIZE_KiB_max": wmax.get("k_vv_x_fwd<float, false>"),
-                                                  "expected_KiB_each_way": 7 * batch * 3072 * 2048 * 4 / 1024},
+                "calibration_k_vv_x_bwd_level2": {"FETCH_SIZE_KiB_max": fmax.get("k_vv_x_bwd"), "WRITE_SIZE_KiB_max": wmax.get("k_vv_x_bwd"),
+                                                  "expected_KiB_each_way": 7 * batch * 1536 * 1024 * 4 / 1024},
                 "source": os.path.relpath(src, ROOT), "batch": batch, "steps": steps_total}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 tot = sum(e["hbm_bytes_per_pair"] for g, e in out.items() if not g.startswith("_"))
