@@ -194,6 +194,7 @@ struct stitch_plan {
     unsigned* wf_ctrl = nullptr;   // per level one band-queue head (16 words apart), then the abort flag
     uint8_t* zt = nullptr;         // zero-tile flags of T, [7*cap][bands][tiles] of level 0 (ZeroTiles); reused level by level
     bool zero_tiles = false;
+    int wf_max_wgs = 2304;  // persistent workgroups of the fused sweep (STITCH_XBYF_WGS)
     unsigned long long* wf_dbg = nullptr;  // STITCH_WAVEFRONT_STAMP=1: [2048][8] segment cycle sums (diagnostics)
     unsigned* h_wf_abort = nullptr;  // pinned copy of the abort flag of the last call
     float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
@@ -307,7 +308,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             double* state_y = p->state + 4 * (size_t)p->cap * 7 * (a.h + 64);
             {
                 StageTimer t(p, s, STITCH_K_VV_XBYF, l);
-                const int wg = (int)std::min<long>(ntiles, 2304);  // 9 workgroups per CU by LDS
+                const int wg = (int)std::min<long>(ntiles, p->wf_max_wgs);  // at most 9 workgroups per CU by LDS
                 if (p->wf_dbg && l == 0) {  // diagnostic build: per-segment cycle sums of the level-0 launch
                     wf.dbg = p->wf_dbg;
                     k_vv_xbyf<true><<<wg, 64, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf);
@@ -935,6 +936,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         p->wf_yg_bytes = sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE;
         p->wf_ctrl = reinterpret_cast<unsigned*>(base + wfc_off);
         p->zt = reinterpret_cast<uint8_t*>(base + zt_off);
+        if (const char* ew = std::getenv("STITCH_XBYF_WGS")) p->wf_max_wgs = std::max(64, atoi(ew));
         const char* ez = std::getenv("STITCH_NO_ZERO_TILES");  // A/B and tests: move the zeros like any other sample
         p->zero_tiles = !(ez && atoi(ez) != 0);
     }
