@@ -1423,6 +1423,25 @@ __device__ __forceinline__ void granules_publish(u64* base, int lane, unsigned t
 // ONE granule with a long sleep between polls; once its tag matches, the whole wavefront reads its six granules,
 // repeating that (rarely) until every tag matches -- the stores of one publish may become visible in any order.
 // Wave-uniform exit; false on timeout / abort.
+// The same read, split in two so that it can be issued early: the seven loads go out BEFORE the next tile's prefetch
+// (loads return in order, so a poll issued behind 16 tile loads would wait for all of them), the check happens after the
+// x sweep.  In the steady state of the pipeline the band above is ahead and the early read already holds the state.
+// (A second tile of prefetch was tried and is slower: more bytes in flight lengthen every queue the hand-off sits in.)
+__device__ __forceinline__ void granules_issue(const u64* base, int lane, u64 g[WF_GRAN]) {
+#pragma unroll
+    for (int i = 0; i < WF_GRAN; ++i) g[i] = __hip_atomic_load((gu64*)(base + i * WAVE + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool granules_accept(const u64 g[WF_GRAN], unsigned tag, double& a, double& b, double& c, unsigned& extra) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < WF_GRAN; ++i) ok &= (unsigned)(g[i] >> 32) == tag;
+    if (!__all(ok)) return false;
+    extra = (unsigned)g[6];
+    a = __longlong_as_double((long long)((g[0] & 0xffffffffu) | (g[1] << 32)));
+    b = __longlong_as_double((long long)((g[2] & 0xffffffffu) | (g[3] << 32)));
+    c = __longlong_as_double((long long)((g[4] & 0xffffffffu) | (g[5] << 32)));
+    return true;
+}
 __device__ __forceinline__ bool granules_consume(const u64* base, int lane, unsigned tag, unsigned* abort, double& a, double& b,
                                                  double& c, unsigned& extra) {
 #ifndef STITCH_WF_POLL
@@ -1529,6 +1548,9 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
         for (int C = wf.NC - 1; C >= 0; --C) {
             const int c0 = C * TS, ncols = min(TS, w - c0);
             const bool tile_zero = next_zero;  // the tile now going to LDS holds +0 only
+            u64* slot = wf.yg + ((size_t)p * wf.NC + C) * WF_GRAN * WAVE;
+            u64 early[WF_GRAN];
+            if (R > 0) granules_issue(slot, lane, early);  // ahead of the prefetch below (in-order return)
             if (!const_rows) {
                 tile_to_lds(tile, lane, pre);
                 if (C > 0) next_zero = fetch_tile(C - 1);  // next tile of the band, in flight during both sweeps
@@ -1583,13 +1605,13 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             stamp(2);  // x sweep
             // ---- causal y sweep, lane = column c0+lane -----------------------------------------------------------
             float* colp = tile + lane;
-            u64* slot = wf.yg + ((size_t)p * wf.NC + C) * WF_GRAN * WAVE;
             double u1, u2, u3;
             unsigned rowbits = 0;
             if (R == 0) {
                 u1 = u2 = u3 = (double)colp[0] / k.sumsq;  // CImg.h:34909
                 rowbits = __float_as_uint(colp[0]);     // the x-blurred row (mask plane: identical for every y)
-            } else if (!granules_consume(slot, lane, (wf.epoch << 12) | (unsigned)R, wf.abort, u1, u2, u3, rowbits)) {
+            } else if (!granules_accept(early, (wf.epoch << 12) | (unsigned)R, u1, u2, u3, rowbits) &&
+                       !granules_consume(slot, lane, (wf.epoch << 12) | (unsigned)R, wf.abort, u1, u2, u3, rowbits)) {
                 dead = true;
                 break;
             }
