@@ -288,11 +288,25 @@ def main():
                 except Exception:
                     traffic = None
             pilot_tot = sum(v[0] for v in pilot.values())
+            # the box's device-to-device copy rate (bytes read + bytes written), for orientation next to the nominal peak
+            csrc = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            cdst = torch.empty_like(csrc)
+            cdst.copy_(csrc)
+            torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(5):
+                cdst.copy_(csrc)
+            c1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * csrc.numel() / (c0.elapsed_time(c1) / 1e3) / 1e9
+            del csrc, cdst
             line["roofline"] = {"bound": "hbm", "kernel": capi.KERNEL_SYMBOLS[dom].replace("<T,", "<float,"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                                 "avg_launch_ms": round(ms / launches, 5), "launches": launches,
                                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                                 "share_of_device_time": round(pilot[dom][0] / pilot_tot, 4),
+                                "device_copy_GBps": round(copy_gbs, 1),
                                 "note": "timed region 2 (one batch in flight, so launches of different batches do not overlap): average over "
                                         "every launch of this kernel symbol (all pyramid levels); HIP events on the launch stream"}
         line["kernels"] = {k_: {"ms_per_pair": round(v[0] / PILOT / B, 4), "launches_per_step": v[1] // PILOT,
