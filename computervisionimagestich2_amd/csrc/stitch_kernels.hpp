@@ -1389,8 +1389,10 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
 // depends on has always been claimed earlier by a workgroup that is running (no residency assumption, no deadlock).
 // The y state travels as 8-byte {tag, word} granules (the data is the flag; relaxed agent-scope atomics = sc1
 // write-through stores / L1-bypassing loads; guide 6, Guideline 16, form R2): six granules per lane for three
-// doubles.  tag = (launch epoch << 12) | (producer band + 1), so the slot of a column block is reused band after
-// band and never has to be cleared.  Every spin is bounded; a timeout raises `abort` for all workgroups.
+// doubles.  tag = (epoch << 12) | (producer band + 1), so the slot of a column block is reused band after band
+// within a launch.  Between launches the host clears the slots with k_clear_words and passes a constant epoch: a
+// per-launch epoch would be frozen by a HIP-graph capture and stale tags of the previous replay would match at
+// once.  Every spin is bounded; a timeout raises `abort` for all workgroups.
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;

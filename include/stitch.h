@@ -138,6 +138,15 @@ int stitch_plan_levels(const stitch_plan *plan, int *level_w, int *level_h);
  * STITCH_WAVEFRONT=<n> levels when that environment variable is set (0 = always separate sweeps).  Results are
  * identical either way. */
 int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
+/* Tuning / A-B switches read at plan creation (none of them changes a result bit):
+ *   STITCH_WAVEFRONT=<n>      fused sweep on exactly n finest levels (0 = never)
+ *   STITCH_NO_FUSE=1          blur and decimation as separate kernels, level-0 mask materialised
+ *   STITCH_NO_SRC_FUSE=1      materialise level 0 (k_compose) instead of gathering it from the frames where it is needed
+ *   STITCH_NO_ZERO_TILES=1    store and re-read all-zero tiles of the blur scratch like any other tile
+ *   STITCH_CROWS_L0=<n>       rows per work-item strip of the level-0 collapse (default 16)
+ *   STITCH_XBYF_WGS=<n>       persistent workgroups of the fused sweep (default 2304)
+ * The stitch_dev_pairs_* launch sequence contains no host synchronisation and no per-launch state in kernel
+ * arguments: it may be captured into a HIP graph and replayed on new contents of the same buffers. */
 
 int stitch_dev_blend_u8(stitch_plan *plan, const uint8_t *d_a, const uint8_t *d_b, uint8_t *d_out, void *stream);
 int stitch_dev_blend_f32(stitch_plan *plan, const float *d_a, const float *d_b, float *d_out, void *stream);
