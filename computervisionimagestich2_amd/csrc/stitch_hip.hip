@@ -192,6 +192,7 @@ struct stitch_plan {
     u64* wf_yg = nullptr;
     size_t wf_yg_bytes = 0;
     unsigned* wf_ctrl = nullptr;   // per level one band-queue head (16 words apart), then the abort flag
+    uint8_t* zi = nullptr;         // [cap][tiles][bands] of level 0: "every pixel of the tile lies outside the frame" (k_src_index)
     uint8_t* zt = nullptr;         // zero-tile flags of T, [7*cap][bands][tiles] of level 0 (ZeroTiles); reused level by level
     bool zero_tiles = false;
     int wf_max_wgs = 2304;  // persistent workgroups of the fused sweep (STITCH_XBYF_WGS)
@@ -255,7 +256,7 @@ int launch_check(const char* what) {
 
 // REDUCE for every level (ImageProcess.cpp:705-715): blur(G_l) into T, decimate T into G_{l+1}.
 template <typename PX>
-int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, bool src) {
+int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, bool src, const ZeroTiles& zi) {
     const int np = 7 * n;  // planes in flight: every launch covers all pairs of the batch
     if (p->wf_levels > 0) k_clear_words<<<1, 256, 0, s>>>((u64*)p->wf_ctrl, WF_CTRL_WORDS / 2);  // band-queue heads + abort flag
     for (int l = 0; l + 1 < p->L; ++l) {
@@ -285,9 +286,9 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             {
                 StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
                 if (src && l == 0)
-                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt);
+                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi);
                 else
-                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt);
+                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{});
             }
             Wavefront wf{};
             wf.yg = p->wf_yg;
@@ -328,9 +329,9 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
                     if (src && l == 0)
-                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt);
+                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi);
                 else
-                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt);
+                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{});
                 }
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
@@ -436,7 +437,7 @@ int dev_blend(stitch_plan* p, const PX* d_a, const PX* d_b, PX* d_out, void* str
     }
     const PairArgs<PX> none{};  // dense canvases: level 0 is in memory
     if ((rc = run_seam_mask<PX>(p, 1, s, none, false))) return rc;
-    if ((rc = run_reduce<PX>(p, 1, s, none, false))) return rc;
+    if ((rc = run_reduce<PX>(p, 1, s, none, false, ZeroTiles{}))) return rc;
     OutPtrs<PX> outs{};
     outs.p[0] = d_out;
     if ((rc = run_collapse<PX>(p, 1, outs, s, none, false))) return rc;
@@ -478,17 +479,26 @@ int dev_pairs(stitch_plan* p, const stitch_pair_desc* d, int n, void* stream) {
     int rc;
     // source-fused: level 0 is a function of the frames, evaluated by its three consumers through an index plane
     bool src = p->src_fuse;
+    ZeroTiles zi{};
+    if (src && p->zero_tiles) {
+        zi.flags = p->zi;
+        zi.h = a.h;
+        zi.NR = a.h / TS;
+        zi.NC = (a.w + TS - 1) / TS;
+    }
     for (int i = 0; i < n; ++i)  // 32-bit element indices and byte offsets into one channel plane
         src = src && (unsigned long long)d[i].fw * d[i].fh * sizeof(PX) < 0xfffffff0ULL && (unsigned long long)d[i].mw * d[i].mh * sizeof(PX) < 0xfffffff0ULL;
     {
         StageTimer t(p, s, STITCH_K_COMPOSE, 0);
-        if (src)
-            k_src_index<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps);
+        if (src) {
+            if (zi.flags) k_fill_bytes<<<64, 256, 0, s>>>(zi.flags, (size_t)n * zi.NR * zi.NC, (uint8_t)1);
+            k_src_index<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps, zi);
+        }
         else
             k_compose<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps);
     }
     if ((rc = run_seam_mask<PX>(p, n, s, pa, src))) return rc;
-    if ((rc = run_reduce<PX>(p, n, s, pa, src))) return rc;
+    if ((rc = run_reduce<PX>(p, n, s, pa, src, zi))) return rc;
     if ((rc = run_collapse<PX>(p, n, outs, s, pa, src))) return rc;
     p->last_stream = s;
     p->pending = true;
@@ -899,6 +909,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     const int NC0 = (v0.w + TS - 1) / TS;
     const size_t yg_off = wf_levels ? take(sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE) : 0;
     const size_t wfc_off = wf_levels ? take(sizeof(unsigned) * WF_CTRL_WORDS) : 0;
+    const size_t zi_off = take((size_t)B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS));
     const size_t zt_off = wf_levels ? take((size_t)7 * B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS)) : 0;
     // x-sweep state [4][lines] followed by the y state the wavefront kernel leaves [4][planes][pitch]
     const size_t state_n = 4 * 7 * B * (size_t)(v0.h + 64) + 4 * 7 * B * (size_t)std::max(v0.h + 64, v0.pitch);
@@ -936,6 +947,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         p->wf_yg_bytes = sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE;
         p->wf_ctrl = reinterpret_cast<unsigned*>(base + wfc_off);
         p->zt = reinterpret_cast<uint8_t*>(base + zt_off);
+        p->zi = reinterpret_cast<uint8_t*>(base + zi_off);
         if (const char* ew = std::getenv("STITCH_XBYF_WGS")) p->wf_max_wgs = std::max(64, atoi(ew));
         const char* ez = std::getenv("STITCH_NO_ZERO_TILES");  // A/B and tests: move the zeros like any other sample
         p->zero_tiles = !(ez && atoi(ez) != 0);

@@ -559,14 +559,31 @@ __device__ __forceinline__ unsigned mosaic_offset(unsigned row, unsigned col) {
     return (row == 0xffffffffu || col == 0xffffffffu) ? off_outside<PX>() : row + col;
 }
 
+// Sparse canvases.  A stitched canvas is mostly empty for either image (the reference blurs and decimates the zeros
+// like everything else), and the recursive filters leave exact +0.0f wherever the input was zero and the state has
+// died out (about 150 samples past the data; the tails of these images are non-negative).  For the levels the fused
+// sweep covers (heights that are multiples of 64), a kernel that produces a 64x64 tile of the blur scratch T made of
+// +0.0f only records one byte instead of storing the tile, and the next kernel takes the zeros from the flag instead
+// of from HBM.  The arithmetic is unchanged (zeros are swept like any other sample); only stores and loads of
+// zeros are skipped.  The test is on the bit pattern, so a -0.0f keeps its tile "non-zero".
+struct ZeroTiles {
+    uint8_t* flags;  // [planes][NC][NR] (bands of one tile column are contiguous), nullptr = feature off for this level
+    int h, NR, NC;   // rows per plane, 64-row bands per plane, 64-column tiles per row
+    __device__ __forceinline__ size_t index(long plane, int band, int tile) const { return ((size_t)plane * NC + tile) * NR + band; }
+};
+
 template <typename PX>
-__global__ __launch_bounds__(256) void k_src_index(PairArgs<PX> pa, float* __restrict__ g0_all, int cw, int ch, int pitch, size_t ps) {
+__global__ __launch_bounds__(256) void k_src_index(PairArgs<PX> pa, float* __restrict__ g0_all, int cw, int ch, int pitch, size_t ps,
+                                                   ZeroTiles zi) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, pr = blockIdx.z;
     if (x >= pitch) return;
     unsigned v = off_outside<PX>();
     int nx, ny;
     if (x < cw && map_to_src(pa.map[pr], (float)x + pa.offx[pr], (float)y + pa.offy[pr], pa.fw[pr], pa.fh[pr], nx, ny))
         v = ((unsigned)ny * (unsigned)pa.fw[pr] + (unsigned)nx) * (unsigned)sizeof(PX);  // the host checked that a plane fits 32 bits
+    // a wavefront is 64 consecutive pixels of one row = one row of one 64x64 tile (the pitch is a multiple of 64): the tile's
+    // "every pixel outside the frame" flag, preset to 1, is cleared by any row that holds a sample (same byte, same value)
+    if (zi.flags && __ballot(v != off_outside<PX>()) != 0 && (threadIdx.x & 63) == 0) zi.flags[zi.index(pr, y >> 6, x >> 6)] = 0;
     reinterpret_cast<unsigned*>(g0_all + (size_t)pr * 7 * ps)[(size_t)y * pitch + x] = v;
 }
 
@@ -764,19 +781,6 @@ __device__ __forceinline__ void tile_store(float* __restrict__ base, int pitch, 
         *reinterpret_cast<f4*>(p + (size_t)(4 * i) * pitch) = *reinterpret_cast<const f4*>(t + (4 * i) * TP);
 }
 
-// Sparse canvases.  A stitched canvas is mostly empty for either image (the reference blurs and decimates the zeros
-// like everything else), and the recursive filters leave exact +0.0f wherever the input was zero and the state has
-// died out (about 150 samples past the data; the tails of these images are non-negative).  For the levels the fused
-// sweep covers (heights that are multiples of 64), a kernel that produces a 64x64 tile of the blur scratch T made of
-// +0.0f only records one byte instead of storing the tile, and the next kernel takes the zeros from the flag instead
-// of from HBM.  The arithmetic is unchanged (zeros are swept like any other sample); only stores and loads of
-// zeros are skipped.  The test is on the bit pattern, so a -0.0f keeps its tile "non-zero".
-struct ZeroTiles {
-    uint8_t* flags;  // [planes][NC][NR] (bands of one tile column are contiguous), nullptr = feature off for this level
-    int h, NR, NC;   // rows per plane, 64-row bands per plane, 64-column tiles per row
-    __device__ __forceinline__ size_t index(long plane, int band, int tile) const { return ((size_t)plane * NC + tile) * NR + band; }
-};
-
 // Level-0 mask without a level-0 mask plane.  The reference's mask[0] is a vertical step (ImageProcess.cpp:690-698):
 // every row is the same function of x, so (when the level height is a multiple of 64, i.e. a 64-row block never
 // straddles planes) the x sweeps generate the step on the fly, compute only the first 64 of its identical rows,
@@ -859,7 +863,7 @@ __device__ __forceinline__ void src_finish(bool warped, f4 pre[16]) {  // raw bi
 template <typename PX, bool SRC>
 __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, float* __restrict__ out, int w, int pitch,
                                                   long lines, VVK k, double* __restrict__ state, MaskL0 mk,
-                                                  typename CollapseSrc<PX, SRC>::type pa, ZeroTiles zt) {
+                                                  typename CollapseSrc<PX, SRC>::type pa, ZeroTiles zt, ZeroTiles zi) {
     __shared__ __attribute__((aligned(16))) float tile[TS * TP];
     const int lane = threadIdx.x;
     const long line0 = (long)blockIdx.x * TS, line = line0 + lane;
@@ -889,6 +893,17 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
     // Element indices of the next tile, produced one tile ahead of the gather that consumes them: loaded from the index
     // plane (frame channels) or computed (the mosaic is a pure shift).
     f4 nidx[SRC ? 16 : 1];
+    // index tile t of this block's band: from the index plane, or all "outside" when k_src_index left the tile's flag set
+    auto index_tile = [&](int t) {
+        if constexpr (SRC) {
+            if (zi.flags && zi.flags[zi.index(src_pr, src_y0 >> 6, t)]) {
+                const float o = __uint_as_float(off_outside<PX>());
+#pragma unroll
+                for (int i = 0; i < 16; ++i) nidx[i] = f4{o, o, o, o};
+            } else
+                tile_load(idx_rows, pitch, t * TS, lane, nidx);
+        }
+    };
     auto gen_tile = [&](int c0, f4 pre[16]) {
         f4 v;
         const int c = c0 + ((lane & 15) << 2);
@@ -916,7 +931,7 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
             src_gather<PX>(rs, nidx, pre);                                     \
             if ((T) + 1 < ntiles) {                                            \
                 if (gen_frame)                                                 \
-                    tile_load(idx_rows, pitch, ((T) + 1) * TS, lane, nidx);    \
+                    index_tile((T) + 1);                                       \
                 else                                                           \
                     mosaic_indices<PX>(ms, ((T) + 1) * TS, lane, src_y0, w, nidx); \
             }                                                                  \
@@ -925,7 +940,7 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
     } while (0)
     if constexpr (SRC) {
         if (gen_frame)
-            tile_load(idx_rows, pitch, 0, lane, nidx);
+            index_tile(0);
         else if (gen_mosaic)
             mosaic_indices<PX>(ms, 0, lane, src_y0, w, nidx);
     }
@@ -2076,6 +2091,9 @@ __global__ __launch_bounds__(256) void k_synth(PX* __restrict__ dst, int w, int 
 // CImg<unsigned char>(const CImg<float>&) (CImg.h:11167-11182).  Values are in [0,255] after the collapse clamp.
 // Zeroes `n` 64-bit words (hand-off granules, queue heads, abort flag).  A kernel rather than hipMemsetAsync so that a
 // captured HIP graph orders it like every other node of the sequence.
+__global__ __launch_bounds__(256) void k_fill_bytes(uint8_t* __restrict__ p, size_t n, uint8_t v) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
 __global__ __launch_bounds__(256) void k_clear_words(u64* __restrict__ p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
 }
