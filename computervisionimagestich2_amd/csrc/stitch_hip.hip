@@ -900,8 +900,10 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     int wf_levels = 0;
     if (const char* e = std::getenv("STITCH_WAVEFRONT"))
         wf_levels = std::max(0, std::min(4, std::atoi(e)));
-    else if (max_pairs >= 2)  // auto: the band pipeline pays where a level has many bands and tiles to stream and other
-                              // pairs' work hides its fill (bands x hand-off latency); a lone pair is faster unfused
+    else if (max_pairs >= 2 || 7L * ((lh[0] + TS - 1) / TS) >= 800)
+        // auto: the band pipeline pays where a launch has many bands in flight (planes x 64-row bands of level 0: 896 for two
+        // 6144x4096 pairs, 1792 for one 24576x16384 pair) to hide its fill (bands x hand-off latency) and the levels have
+        // enough tiles to stream; a lone 6144x4096 pair (448 bands) is faster unfused
         while (wf_levels < 2 && wf_levels < L - 1 && lw[wf_levels] >= 1024 && lh[wf_levels] >= 1024) ++wf_levels;
     if (o.blur_kind != 0 || std::getenv("STITCH_NO_FUSE") || o.sigma < 0.5f) wf_levels = 0;
     wf_levels = std::min(wf_levels, L - 1);

@@ -134,7 +134,8 @@ void stitch_plan_destroy(stitch_plan *plan);
 size_t stitch_plan_workspace_bytes(const stitch_plan *plan);
 int stitch_plan_levels(const stitch_plan *plan, int *level_w, int *level_h);
 /* Number of finest pyramid levels whose anticausal-x and causal-y sweeps run fused (k_vv_xbyf).  Chosen at plan
- * creation: for batched plans (max_pairs >= 2) the levels of at least 1024 x 1024, at most two -- or exactly
+ * creation: for batched plans (max_pairs >= 2) and for single pairs at least 7360 rows high (many row bands in flight),
+ * the levels of at least 1024 x 1024, at most two -- or exactly
  * STITCH_WAVEFRONT=<n> levels when that environment variable is set (0 = always separate sweeps).  Results are
  * identical either way. */
 int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
