@@ -196,6 +196,7 @@ struct stitch_plan {
     uint8_t* zt = nullptr;         // zero-tile flags of T, [7*cap][bands][tiles] of level 0 (ZeroTiles); reused level by level
     bool zero_tiles = false;
     int wf_max_wgs = 2304;  // persistent workgroups of the fused sweep (STITCH_XBYF_WGS)
+    int wf_early_read = 1;  // STITCH_XBYF_EARLY=0: poll for the hand-off only when it is needed
     unsigned long long* wf_dbg = nullptr;  // STITCH_WAVEFRONT_STAMP=1: [2048][8] segment cycle sums (diagnostics)
     unsigned* h_wf_abort = nullptr;  // pinned copy of the abort flag of the last call
     float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
@@ -304,6 +305,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             wf.epoch = 1;
             wf.mask_l0 = mk.enabled;
             wf.zt = zt;
+            wf.early_read = p->wf_early_read;
             const long ntiles = (long)wf.NP * wf.NR;  // one persistent wavefront per row band
             // the x-sweep state lives in state[0 .. 4*lines); the y state the kernel leaves goes behind it
             double* state_y = p->state + 4 * (size_t)p->cap * 7 * (a.h + 64);
@@ -951,6 +953,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         p->zt = reinterpret_cast<uint8_t*>(base + zt_off);
         p->zi = reinterpret_cast<uint8_t*>(base + zi_off);
         if (const char* ew = std::getenv("STITCH_XBYF_WGS")) p->wf_max_wgs = std::max(64, atoi(ew));
+        if (const char* ee = std::getenv("STITCH_XBYF_EARLY")) p->wf_early_read = atoi(ee) != 0;
         const char* ez = std::getenv("STITCH_NO_ZERO_TILES");  // A/B and tests: move the zeros like any other sample
         p->zero_tiles = !(ez && atoi(ez) != 0);
     }

@@ -1420,6 +1420,7 @@ struct Wavefront {
     int NR, NC, NP;
     unsigned epoch;
     ZeroTiles zt;             // zero-tile flags of T at this level (see ZeroTiles)
+    int early_read;           // read the hand-off state ahead of the tile prefetch (granules_issue)
     unsigned long long* dbg;  // diagnostic build only: [workgroups][8] cycle sums per segment
 };
 
@@ -1567,7 +1568,8 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             const bool tile_zero = next_zero;  // the tile now going to LDS holds +0 only
             u64* slot = wf.yg + ((size_t)p * wf.NC + C) * WF_GRAN * WAVE;
             u64 early[WF_GRAN];
-            if (R > 0) granules_issue(slot, lane, early);  // ahead of the prefetch below (in-order return)
+            const bool early_on = R > 0 && wf.early_read;
+            if (early_on) granules_issue(slot, lane, early);  // ahead of the prefetch below (in-order return)
             if (!const_rows) {
                 tile_to_lds(tile, lane, pre);
                 if (C > 0) next_zero = fetch_tile(C - 1);  // next tile of the band, in flight during both sweeps
@@ -1627,7 +1629,7 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             if (R == 0) {
                 u1 = u2 = u3 = (double)colp[0] / k.sumsq;  // CImg.h:34909
                 rowbits = __float_as_uint(colp[0]);     // the x-blurred row (mask plane: identical for every y)
-            } else if (!granules_accept(early, (wf.epoch << 12) | (unsigned)R, u1, u2, u3, rowbits) &&
+            } else if (!(early_on && granules_accept(early, (wf.epoch << 12) | (unsigned)R, u1, u2, u3, rowbits)) &&
                        !granules_consume(slot, lane, (wf.epoch << 12) | (unsigned)R, wf.abort, u1, u2, u3, rowbits)) {
                 dead = true;
                 break;
