@@ -1,0 +1,67 @@
+"""Randomised parity run: batched pairs with random geometry against the CPU oracle, on canvases where the fused sweep,
+the source fusion and the zero-tile flags are all active (forced with STITCH_WAVEFRONT).  Test infrastructure (uses oracle/)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+
+def run(seed, N, verbose=True):
+    """-> (pairs compared, mismatches).  STITCH_WAVEFRONT etc. are read when a plan is created: set them before calling."""
+    import torch
+    import oracle_lib
+    from computervisionimagestich2_amd import capi
+    O = oracle_lib.Oracle()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    bad = done = 0
+    for case in range(N):
+        bad, done = _case(case, rng, O, capi, torch, dev, bad, done, verbose)
+    return done, bad
+
+
+def _case(case, rng, O, capi, torch, dev, bad, done, verbose):
+    if True:
+        ch = 64 * int(rng.integers(2, 9))
+        cw = 2 * int(rng.integers(max(33, ch // 4 + 1), ch))  # even, within a factor two of the height (else the pyramid degenerates)
+        B = int(rng.integers(1, 4))
+        dtype = np.float32 if rng.random() < 0.6 else np.uint8
+        plan = capi.Plan(cw, ch, max_pairs=B)
+        items, refs = [], []
+        for i in range(B):
+            fw, fh = int(rng.integers(40, cw)), int(rng.integers(40, ch + 60))
+            mw, mh = int(rng.integers(cw // 3, cw + 40)), int(rng.integers(ch // 2, ch + 40))
+            ox, oy = int(rng.integers(-30, 30)), int(rng.integers(-30, 30))
+            P = [1 + rng.normal() * 0.02, rng.normal() * 0.02, rng.normal() * 2e-5, -rng.uniform(0, cw - 40), rng.normal() * 0.02, 1 + rng.normal() * 0.02,
+                 rng.normal() * 1e-5, rng.normal() * 15]
+            offx, offy = (0.0, 0.0) if rng.random() < 0.5 else (float(np.float32(rng.normal() * 3)), float(np.float32(rng.normal() * 3)))
+            F, M = O.synth(fw, fh, 2 * case + 1, dtype), O.synth(mw, mh, 2 * case, dtype)
+            rc, ref = O.pair(F, P, offx, offy, M, ox, oy, cw, ch)
+            items.append((torch.from_numpy(F).to(dev), P, offx, offy, torch.from_numpy(M).to(dev), ox, oy,
+                          torch.empty((3, ch, cw), dtype=torch.uint8 if dtype == np.uint8 else torch.float32, device=dev)))
+            refs.append((rc, ref))
+        outs = plan.pairs(items)
+        for i in range(B):
+            rc, ref = refs[i]
+            try:
+                plan.status(i)
+                grc = 0
+            except capi.StitchError as e:
+                grc = e.code
+            if grc != rc:
+                print("STATUS MISMATCH", case, i, grc, rc); bad += 1
+            elif rc == 0:
+                same = np.array_equal(outs[i].cpu().numpy().view(np.uint8), ref.view(np.uint8))
+                done += 1
+                if not same:
+                    d = outs[i].cpu().numpy().astype(np.float64) - ref.astype(np.float64)
+                    print("PIXEL MISMATCH", case, i, (cw, ch, B, dtype.__name__), np.abs(d).max(), (d != 0).sum()); bad += 1
+        plan.close()
+        return bad, done
+
+
+if __name__ == "__main__":
+    os.environ.setdefault("STITCH_WAVEFRONT", "2")
+    done, bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 7, int(sys.argv[2]) if len(sys.argv) > 2 else 30)
+    print(f"fuzz: {done} pairs compared bit for bit, {bad} mismatches, fused levels forced = {os.environ['STITCH_WAVEFRONT']}")
+    sys.exit(1 if bad else 0)

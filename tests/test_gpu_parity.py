@@ -1,10 +1,14 @@
 """GPU parity: the HIP path, called through the C ABI (include/stitch.h), against the oracle on the same seeded
 inputs.  Bar: bit-exact for unsigned-char images, histogram bins and seam integers; for float frames the
 north-star tolerance is 1e-4 per channel -- the tests assert bit-equality first and report the max error."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 TOL_F32 = 1e-4  # BASELINE.json north_star: "within 1e-4 per channel for the warped/blended float pixels"
 
@@ -395,3 +399,18 @@ def test_zero_tile_flags(st, gpu, oracle, no_zero_tiles, negative, monkeypatch):
             plan.status(slot)
             assert np.array_equal(outs[slot].cpu().numpy().view(np.uint32), refs[i].view(np.uint32)), (rep, i)
     plan.close()
+
+
+@pytest.mark.parametrize("wavefront,seed", [("2", 3), ("0", 4)])
+def test_random_pairs_against_oracle(st, gpu, oracle, wavefront, seed, monkeypatch):
+    """Randomised geometry (scripts/fuzz_pairs.py): batches of 1-3 pairs, random canvas sizes (heights multiples of 64),
+    frame / mosaic sizes, bilinear maps, fractional and integer offsets, both pixel types; outputs AND error codes
+    (empty middle row, zero overlap) must equal the oracle's.  With the fused sweep forced on two levels every fast path is
+    active at these sizes (source fusion, implicit mask, zero-tile flags, fused sweep); with 0 the separate sweeps run."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_pairs", os.path.join(os.path.dirname(HERE), "scripts", "fuzz_pairs.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    monkeypatch.setenv("STITCH_WAVEFRONT", wavefront)
+    done, bad = fz.run(seed, 16)
+    assert bad == 0 and done >= 4, (done, bad)  # the other cases ended in the same error code on both sides
