@@ -62,3 +62,34 @@ def test_canvas_bbox_and_feature_updates_are_host_arithmetic(st, oracle):
         assert np.array_equal(a, b)
     for a, b in zip(st.capi.shift_points(x, y, -230, -4), oracle.shift_points(x, y, -230, -4)):
         assert np.array_equal(a, b)
+
+
+def test_bmp_header_arithmetic_is_host_only(st, oracle):
+    """stitch_bmp_parse / stitch_bmp_file_bytes are host arithmetic on the 54-byte header (CImg.h:48413-48441): they work
+    without a GPU and agree with the oracle's parse field by field for every layout knob, and refuse what CImg's 24/32-bit
+    branch does not cover."""
+    import ctypes as C
+    from computervisionimagestich2_amd import capi
+    from oracle_lib import BmpInfo, make_bmp
+    img = oracle.synth(37, 11, 2)
+    for kw in [dict(), dict(bpp=32), dict(top_down=True), dict(header_size=108), dict(extra_gap=10), dict(extra_gap=1), dict(size_field=0),
+               dict(size_field=60), dict(truncate=7), dict(truncate=200), dict(bpp=32, top_down=True, header_size=124, extra_gap=3)]:
+        data = make_bmp(img, **kw)
+        got = capi.bmp_parse(data[:54], len(data))
+        buf = np.frombuffer(data, np.uint8)
+        want = BmpInfo()
+        oracle.lib.oracle_bmp_parse.restype = C.c_int
+        assert oracle.lib.oracle_bmp_parse(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), C.byref(want)) == 0
+        for f, _ in BmpInfo._fields_:
+            assert getattr(got, f) == getattr(want, f), (kw, f)
+    assert capi.lib().stitch_bmp_file_bytes(37, 11) == 54 + 112 * 11 == len(oracle.bmp_encode(img))
+    assert capi.lib().stitch_bmp_file_bytes(0, 5) == 0
+    good = bytearray(make_bmp(img))
+    for off, patch in [(0, b"XM"), (0x1C, bytes([8, 0])), (0x1E, bytes([1, 0, 0, 0])), (0x16, bytes([0, 0, 0, 0]))]:
+        bad = bytearray(good)
+        bad[off:off + len(patch)] = patch
+        try:
+            capi.bmp_parse(bytes(bad[:54]), len(bad))
+            raise AssertionError("accepted a header CImg's 24/32-bit branch does not cover")
+        except capi.StitchError as e:
+            assert e.code == capi.ERR_ARG
