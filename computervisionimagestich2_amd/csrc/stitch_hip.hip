@@ -494,7 +494,7 @@ int dev_pairs(stitch_plan* p, const stitch_pair_desc* d, int n, void* stream) {
         StageTimer t(p, s, STITCH_K_COMPOSE, 0);
         if (src) {
             if (zi.flags) k_fill_bytes<<<64, 256, 0, s>>>(zi.flags, (size_t)n * zi.NR * zi.NC, (uint8_t)1);
-            k_src_index<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps, zi);
+            k_src_index<PX><<<grid_xy(a.pitch, (a.h + SI_ROWS - 1) / SI_ROWS, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps, zi);
         }
         else
             k_compose<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps);

@@ -572,19 +572,28 @@ struct ZeroTiles {
     __device__ __forceinline__ size_t index(long plane, int band, int tile) const { return ((size_t)plane * NC + tile) * NR + band; }
 };
 
+constexpr int SI_ROWS = 8;  // rows per workgroup of k_src_index (a one-row workgroup is launch-bound: 393k workgroups per batch)
 template <typename PX>
 __global__ __launch_bounds__(256) void k_src_index(PairArgs<PX> pa, float* __restrict__ g0_all, int cw, int ch, int pitch, size_t ps,
                                                    ZeroTiles zi) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, pr = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, pr = blockIdx.z;
     if (x >= pitch) return;
-    unsigned v = off_outside<PX>();
-    int nx, ny;
-    if (x < cw && map_to_src(pa.map[pr], (float)x + pa.offx[pr], (float)y + pa.offy[pr], pa.fw[pr], pa.fh[pr], nx, ny))
-        v = ((unsigned)ny * (unsigned)pa.fw[pr] + (unsigned)nx) * (unsigned)sizeof(PX);  // the host checked that a plane fits 32 bits
-    // a wavefront is 64 consecutive pixels of one row = one row of one 64x64 tile (the pitch is a multiple of 64): the tile's
-    // "every pixel outside the frame" flag, preset to 1, is cleared by any row that holds a sample (same byte, same value)
-    if (zi.flags && __ballot(v != off_outside<PX>()) != 0 && (threadIdx.x & 63) == 0) zi.flags[zi.index(pr, y >> 6, x >> 6)] = 0;
-    reinterpret_cast<unsigned*>(g0_all + (size_t)pr * 7 * ps)[(size_t)y * pitch + x] = v;
+    const MapP m = pa.map[pr];
+    const float offx = pa.offx[pr], offy = pa.offy[pr];
+    const int fw = pa.fw[pr], fh = pa.fh[pr];
+    unsigned* __restrict__ idx = reinterpret_cast<unsigned*>(g0_all + (size_t)pr * 7 * ps);
+    const int y0 = blockIdx.y * SI_ROWS, y1 = min(y0 + SI_ROWS, ch);
+    for (int y = y0; y < y1; ++y) {
+        unsigned v = off_outside<PX>();
+        int nx, ny;
+        if (x < cw && map_to_src(m, (float)x + offx, (float)y + offy, fw, fh, nx, ny))
+            v = ((unsigned)ny * (unsigned)fw + (unsigned)nx) * (unsigned)sizeof(PX);  // the host checked that a plane fits 32 bits
+        // a wavefront is 64 consecutive pixels of one row = one row of one 64x64 tile (the pitch is a multiple of 64): the
+        // tile's "every pixel outside the frame" flag, preset to 1, is cleared by any row that holds a sample (same byte,
+        // same value)
+        if (zi.flags && __ballot(v != off_outside<PX>()) != 0 && (threadIdx.x & 63) == 0) zi.flags[zi.index(pr, y >> 6, x >> 6)] = 0;
+        idx[(size_t)y * pitch + x] = v;
+    }
 }
 
 template <typename PX>
