@@ -245,14 +245,15 @@ def test_config5_size_single_gpu_against_oracle(st, gpu, oracle):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"within tolerance ({err}) but not bit-equal"
 
 
-def test_fused_sweep_under_concurrent_load(st, gpu, oracle):
+@pytest.mark.parametrize("fw,fh,cw,ch", [(1500, 1100, 2200, 1100), (1500, 1088, 2176, 1088)])
+def test_fused_sweep_under_concurrent_load(st, gpu, oracle, fw, fh, cw, ch):
     """The band-pipeline sweep (inter-workgroup granule hand-offs) while the chip is busy: three batched plans of
-    three pairs each in flight on three HIP streams, repeated with fresh epochs, at a size where the fused sweep is
-    chosen automatically (levels >= 1024 x 1024) and the last band / column block are partial.  Every output of every
-    repetition must equal the oracle's."""
+    three pairs each in flight on three HIP streams, repeated, at sizes where the fused sweep is chosen automatically
+    (levels >= 1024 x 1024): 2200 x 1100 has a partial last band and column block and a materialised level 0;
+    2176 x 1088 (a multiple of 64 rows) runs source-fused with the implicit mask and the zero-tile flags.  Every output
+    of every repetition must equal the oracle's."""
     import torch
     from computervisionimagestich2_amd import capi
-    fw, fh, cw, ch = 1500, 1100, 2200, 1100
     S, B, REPS = 3, 3, 4
     plans = [capi.Plan(cw, ch, max_pairs=B) for _ in range(S)]
     assert plans[0].fused_sweep_levels >= 1
