@@ -6,7 +6,7 @@ import torch
 from computervisionimagestich2_amd import capi
 dev = torch.device("cuda:0")
 os.environ["STITCH_WAVEFRONT"] = "1"
-for (ch, B) in ((4096, 2), (2048, 4), (1024, 8), (4096, 4), (2048, 8)):
+for (ch, B) in ((4096, 2), (2048, 4), (4096, 4), (2048, 8)):  # a 6144x1024 canvas has a degenerate pyramid
     cw, fw, fh = 6144, 4096, ch
     plan = capi.Plan(cw, ch, max_pairs=B)
     items = [(capi.dev_synth(fw, fh, 2 * i + 1, torch.float32, dev), [1.0, 0.002, 1e-6, -2048.0 - 8 * i, -0.001, 1.0, 5e-7, 1.5], 0.0, 0.0,
