@@ -2,7 +2,7 @@
 """bench.py -- warp+blend MPix/s at 4096x4096x3 f32 (BASELINE.json), one process per GPU.
 
 A step = one pass of the hot path (warp + move + multi-band blend) over synthetic input: --streams (default 4)
-batches of --batch (default 4) independent config-2 pairs per rank (two 4096x4096x3 f32 frames -> 6144x4096x3 f32
+batches of --batch (default 8) independent config-2 pairs per rank (two 4096x4096x3 f32 frames -> 6144x4096x3 f32
 mosaic each; pair i of the config-4 family has p[3] = -2048 - 8i); a batch is ONE launch sequence of a batched plan
 on its own HIP stream.  Frames are generated on the device before the timed
 region, so every input is resident in HBM when timing starts.  Pairs are independent: each rank works on its own
@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="independent pairs per batch (one launch sequence)")
+    ap.add_argument("--batch", type=int, default=8, help="independent pairs per batch (one launch sequence)")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU, each on its own HIP stream")
     ap.add_argument("--frame", type=int, default=4096, help="frame edge (4096 = the metric's configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

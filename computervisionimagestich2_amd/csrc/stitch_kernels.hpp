@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void k_move(const PX* __restrict__ src, int sw
 // ImageProcess.cpp:218-224 + :680-681.  Level-0 planes of pair b: [a0 a1 a2 b0 b1 b2 mask], pitched, plane
 // stride ps, pairs stacked (7*ps apart).  The zero canvases of the reference are implicit: an out-of-range pixel
 // is written as 0.  A launch covers every pair of the batch (blockIdx.z = pair).
-constexpr int MAXB = 8;  // pairs per plan / launch
+constexpr int MAXB = 16;  // pairs per plan / launch
 template <typename PX>
 struct PairArgs {
     const PX* frame[MAXB];

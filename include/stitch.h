@@ -125,7 +125,7 @@ int stitch_dev_move_f32(const float *d_src, int sw, int sh, int ox, int oy, floa
  * the blur scratch, the collapse chain, the resize tables, the seam record).  Create it once per canvas size
  * on the device that will run it; calls on one plan must be serialised by the caller (one stream at a time). */
 int stitch_plan_create(int cw, int ch, const stitch_blend_opts *opts, stitch_plan **plan_out);
-/* Workspace for up to max_pairs (1..8) independent pairs of the same canvas size processed by ONE launch sequence
+/* Workspace for up to max_pairs (1..16) independent pairs of the same canvas size processed by ONE launch sequence
  * (every kernel covers all pairs: the batch configs of BASELINE.json -- more independent lines per launch for the
  * recursive filters, fewer launches per pair). */
 int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts *opts, int max_pairs, stitch_plan **plan_out);

@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 steps_total = None  # derived below: k_seam runs once per step
 
 GROUP = {"k_compose": "compose", "k_src_index": "compose", "k_seam": "seam", "k_mask": "mask", "k_vv_x_fwd": "vv_x_fwd",
