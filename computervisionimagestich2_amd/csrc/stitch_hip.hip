@@ -409,7 +409,9 @@ int run_seam_mask(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, 
     const Level& a = p->lv[0];
     {
         StageTimer t(p, s, STITCH_K_SEAM, 0);
-        k_seam<PX><<<n, 1024, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam, pa, src ? 1 : 0);
+        // 256 work-items, not 1024: a 16-wavefront workgroup waits for a CU with that much room when other batches fill the chip
+        // (1.7 ms per launch with four batches in flight)
+        k_seam<PX><<<n, 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam, pa, src ? 1 : 0);
     }
     if (!p->mask_opt) {
         StageTimer t(p, s, STITCH_K_MASK, 0);

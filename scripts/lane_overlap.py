@@ -53,3 +53,22 @@ print("kernels running at once: " + "  ".join(f"{k}: {100 * v / tot:.1f}%" for k
 print(f"{'kernel':40s} {'running %':>10s} {'avg others':>11s}")
 for fam, v in sorted(fam_time.items(), key=lambda kv: -kv[1]):
     print(f"{fam[:40]:40s} {100 * v / tot:10.1f} {fam_company[fam] / v:11.2f}")
+
+# ---- where a batch's own time goes: duration of its launches by number of workgroups (coarse pyramid levels = small grids)
+rows2 = []
+for r in csv.DictReader(open(f)):
+    n = r["Kernel_Name"]
+    if "sk::" not in n:
+        continue
+    s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if e_ <= t_lo or s_ >= t_hi:
+        continue
+    wgs = 1
+    for ax in "XYZ":
+        wgs *= max(1, int(r["Grid_Size_" + ax]) // max(1, int(r["Workgroup_Size_" + ax])))
+    rows2.append((wgs, e_ - s_))
+tot2 = sum(d for _, d in rows2)
+print("\nlaunch time by grid size (share of the summed launch durations = of the batches' own time):")
+for lo, hi in ((0, 64), (64, 512), (512, 4096), (4096, 1 << 40)):
+    sel = [d for w, d in rows2 if lo <= w < hi]
+    print(f"  {lo:>5d} <= workgroups < {hi if hi < 1 << 40 else 'inf':>5}: {100 * sum(sel) / tot2:5.1f} %  ({len(sel)} launches, mean {sum(sel) / max(1, len(sel)) / 1e3:.1f} us)")
