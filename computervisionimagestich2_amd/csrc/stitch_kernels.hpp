@@ -787,7 +787,7 @@ __device__ __forceinline__ void tile_store(float* __restrict__ base, int pitch, 
     const float* t = tile + (lane >> 4) * TP + ((lane & 15) << 2);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-        *reinterpret_cast<f4*>(p + (size_t)(4 * i) * pitch) = *reinterpret_cast<const f4*>(t + (4 * i) * TP);
+        __builtin_nontemporal_store(*reinterpret_cast<const f4*>(t + (4 * i) * TP), reinterpret_cast<f4*>(p + (size_t)(4 * i) * pitch));
 }
 
 // Level-0 mask without a level-0 mask plane.  The reference's mask[0] is a vertical step (ImageProcess.cpp:690-698):
@@ -811,7 +811,7 @@ __device__ __forceinline__ void tile_store_rows(float* __restrict__ base, int pi
 #pragma unroll
     for (int i = 0; i < 16; ++i)
         if ((lane >> 4) + 4 * i < nrows)
-            *reinterpret_cast<f4*>(p + (size_t)(4 * i) * pitch) = *reinterpret_cast<const f4*>(t + (4 * i) * TP);
+            __builtin_nontemporal_store(*reinterpret_cast<const f4*>(t + (4 * i) * TP), reinterpret_cast<f4*>(p + (size_t)(4 * i) * pitch));
 }
 
 // Source-fused level 0: plane byte offsets of one 64x64 tile in tile_load's element-to-lane layout (or "outside"),
@@ -1955,7 +1955,10 @@ __global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_al
                 v = 255.f;
             else if (v < 0.f)
                 v = 0.f;
-            out[(size_t)y * opitch + x + c * ops] = px_store<OUT>(v);
+            if (DENSE)  // the finished mosaic is not read again by this sequence
+                __builtin_nontemporal_store(px_store<OUT>(v), &out[(size_t)y * opitch + x + c * ops]);
+            else
+                out[(size_t)y * opitch + x + c * ops] = px_store<OUT>(v);
         }
     }
 }
