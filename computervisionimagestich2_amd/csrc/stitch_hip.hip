@@ -201,6 +201,7 @@ struct stitch_plan {
     unsigned* h_wf_abort = nullptr;  // pinned copy of the abort flag of the last call
     float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
     bool mask_opt = false;  // level-0 mask handled implicitly (Van Vliet, level-0 height a multiple of 64)
+    int crows_ln = 4 * CROWS;  // rows per strip of the collapse at levels >= 1 (STITCH_CROWS_LN): slower alone than 8, fewer bytes with other batches in flight
     int crows_l0 = 2 * CROWS;  // rows per work-item strip of the level-0 collapse (fewer re-reads of level-1 rows)
     bool src_fuse = false;  // pairs: level-0 planes evaluated from the frames by their consumers, k_compose never runs
     SeamDev* d_seam = nullptr;
@@ -396,9 +397,9 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
         else {
             OutPtrs<float> eo{};
             eo.p[0] = a.e;
-            k_collapse<float, false><<<grid_xy(a.pitch, (a.h + CROWS - 1) / CROWS, n), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w,
+            k_collapse<float, false><<<grid_xy(a.pitch, (a.h + p->crows_ln - 1) / p->crows_ln, n), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w,
                                                                               nx.h, nx.pitch, nx.ps, tb, eo, a.pitch, a.ps, nullptr,
-                                                                              NoPairArgs{}, 0, CROWS);
+                                                                              NoPairArgs{}, 0, p->crows_ln);
         }
     }
     return launch_check("collapse");
@@ -964,6 +965,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     p->mask_opt = !p->no_fuse && o.blur_kind == 0 && !p->blur_skip && L >= 2 && v0.w > 1 && v0.h > 1 && (v0.h % 64) == 0;
     {
         if (const char* c = getenv("STITCH_CROWS_L0")) p->crows_l0 = std::max(1, atoi(c));
+        if (const char* c = getenv("STITCH_CROWS_LN")) p->crows_ln = std::max(1, atoi(c));
         const char* e = getenv("STITCH_NO_SRC_FUSE");  // A/B and tests: keep S1 as its own kernel (k_compose)
         p->src_fuse = p->mask_opt && !(e && atoi(e) != 0);
     }
