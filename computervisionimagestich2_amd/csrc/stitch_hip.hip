@@ -202,7 +202,7 @@ struct stitch_plan {
     float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
     bool mask_opt = false;  // level-0 mask handled implicitly (Van Vliet, level-0 height a multiple of 64)
     int crows_ln = 4 * CROWS;  // rows per strip of the collapse at levels >= 1 (STITCH_CROWS_LN): slower alone than 8, fewer bytes with other batches in flight
-    int crows_l0 = 2 * CROWS;  // rows per work-item strip of the level-0 collapse (fewer re-reads of level-1 rows)
+    int crows_l0 = 4 * CROWS;  // rows per work-item strip of the level-0 collapse (fewer re-reads of level-1 rows)
     bool src_fuse = false;  // pairs: level-0 planes evaluated from the frames by their consumers, k_compose never runs
     SeamDev* d_seam = nullptr;
     SeamDev* h_seam = nullptr;  // pinned

@@ -144,7 +144,7 @@ int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
  *   STITCH_NO_FUSE=1          blur and decimation as separate kernels, level-0 mask materialised
  *   STITCH_NO_SRC_FUSE=1      materialise level 0 (k_compose) instead of gathering it from the frames where it is needed
  *   STITCH_NO_ZERO_TILES=1    store and re-read all-zero tiles of the blur scratch like any other tile
- *   STITCH_CROWS_L0=<n>       rows per work-item strip of the level-0 collapse (default 16)
+ *   STITCH_CROWS_L0=<n>       rows per work-item strip of the level-0 collapse (default 32)
  *   STITCH_CROWS_LN=<n>       the same for the levels above (default 32)
  *   STITCH_XBYF_WGS=<n>       persistent workgroups of the fused sweep (default 2304)
  *   STITCH_XBYF_EARLY=0       fused sweep: poll for the hand-off only when it is needed (default: read it ahead of the prefetch)
