@@ -1565,14 +1565,16 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             tile_load(base, pitch, C * TS, lane, pre);
             return false;
         };
-        bool next_zero = false;
+        bool next_zero = false, spec = true;
         if (!const_rows) next_zero = fetch_tile(wf.NC - 1);
         for (int C = wf.NC - 1; C >= 0; --C) {
             const int c0 = C * TS, ncols = min(TS, w - c0);
             const bool tile_zero = next_zero;  // the tile now going to LDS holds +0 only
             u64* slot = wf.yg + ((size_t)p * wf.NC + C) * WF_GRAN * WAVE;
             u64 early[WF_GRAN];
-            const bool early_on = R > 0 && wf.early_read;
+            // speculation is dropped while it fails (the band above is not ahead: the seven loads would only be repeated
+            // by the poll) and probed again every fourth tile
+            const bool early_on = R > 0 && wf.early_read && (spec || (C & 3) == 0);
             if (early_on) granules_issue(slot, lane, early);  // ahead of the prefetch below (in-order return)
             if (!const_rows) {
                 tile_to_lds(tile, lane, pre);
@@ -1633,10 +1635,13 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             if (R == 0) {
                 u1 = u2 = u3 = (double)colp[0] / k.sumsq;  // CImg.h:34909
                 rowbits = __float_as_uint(colp[0]);     // the x-blurred row (mask plane: identical for every y)
-            } else if (!(early_on && granules_accept(early, (wf.epoch << 12) | (unsigned)R, u1, u2, u3, rowbits)) &&
-                       !granules_consume(slot, lane, (wf.epoch << 12) | (unsigned)R, wf.abort, u1, u2, u3, rowbits)) {
-                dead = true;
-                break;
+            } else {
+                const bool hit = early_on && granules_accept(early, (wf.epoch << 12) | (unsigned)R, u1, u2, u3, rowbits);
+                if (early_on) spec = hit;
+                if (!hit && !granules_consume(slot, lane, (wf.epoch << 12) | (unsigned)R, wf.abort, u1, u2, u3, rowbits)) {
+                    dead = true;
+                    break;
+                }
             }
             stamp(3);  // y state wait
             const float rowv = __uint_as_float(rowbits);
