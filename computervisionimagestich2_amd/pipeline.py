@@ -70,12 +70,15 @@ class PairStitcher:
         self.plan.close()
 
 
-def stitch_chain(frames, steps, opts=None, finish=True, num=19.0, den=20.0):
+def stitch_chain(frames, steps, opts=None, finish=True, num=19.0, den=20.0, plans=None):
     """The hot-path calls of ImageProcess::matching for a recorded stitch order, device resident.
 
     frames: list of (3,H,W) uint8 device tensors (unprojected).  steps: list of dicts with keys
     src (index of the frame to warp), p (8 doubles), offx, offy, ox, oy, cw, ch -- what the reference passes at
     ImageProcess.cpp:218-230; the first mosaic is projection(frames[start]).
+    plans: optional dict kept by the caller across calls; the workspace of every canvas size met is created once and
+    reused (a camera rig stitches every frame with the same geometry: without it half of a small panorama's time is
+    the creation of the three workspaces).  Close them with close_plans(plans).
     Returns the final uint8 mosaic tensor (after equalisation + luminance mix when finish=True, :237-268)."""
     proj = {}
 
@@ -85,14 +88,35 @@ def stitch_chain(frames, steps, opts=None, finish=True, num=19.0, den=20.0):
         return proj[i]
 
     result = projected(steps[0]["start"])
+    used = []
     for st in steps:
-        plan = capi.Plan(st["cw"], st["ch"], opts)
+        key = (st["cw"], st["ch"])
+        plan = plans.get(key) if plans is not None else None
+        if plan is None:
+            plan = capi.Plan(st["cw"], st["ch"], opts)
+            if plans is not None:
+                plans[key] = plan
+        elif plan in used:  # the same workspace twice in one chain: its seam record must be read before it is overwritten
+            plan.status()
         result = plan.pair(projected(st["src"]), st["p"], st["offx"], st["offy"], result, st["ox"], st["oy"])
-        plan.status()
-        plan.close()
+        used.append(plan)
     if finish:
         capi.dev_finish(result, num, den)
+    # the steps only depend on each other on the device; their seam scans are checked once, at the end (raises StitchError)
+    try:
+        for plan in used:
+            plan.status()
+    finally:
+        if plans is None:
+            for plan in used:
+                plan.close()
     return result
+
+
+def close_plans(plans):
+    for plan in plans.values():
+        plan.close()
+    plans.clear()
 
 
 def levels_of(cw, ch, level_rule=0):
