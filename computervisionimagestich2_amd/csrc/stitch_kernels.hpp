@@ -875,7 +875,17 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
                                                   typename CollapseSrc<PX, SRC>::type pa, ZeroTiles zt, ZeroTiles zi) {
     __shared__ __attribute__((aligned(16))) float tile[TS * TP];
     const int lane = threadIdx.x;
-    const long line0 = (long)blockIdx.x * TS, line = line0 + lane;
+    long blk = blockIdx.x;
+    if (SRC && mk.enabled && (mk.h / TS) % 8 == 0) {
+        // Source-fused level 0: the three channel sweeps of a band read the same index tiles.  Workgroups go round-robin
+        // over the 8 XCDs (each with its own L2), so the planes of a pair are interleaved in groups of 8 bands: the seven
+        // blocks of one band are then 8 apart -- same XCD, dispatched together -- and the index tile is fetched from HBM
+        // once instead of three times.  (Plain order: plane-major, the channels of a band 64 blocks apart in time.)
+        const long nr = mk.h / TS, per_pair = 7 * nr, pr_ = blk / per_pair, r = blk % per_pair;
+        const long band = (r / 56) * 8 + r % 8, q = (r / 8) % 7;
+        blk = pr_ * per_pair + q * nr + band;
+    }
+    const long line0 = blk * TS, line = line0 + lane;
     const float* ib = in + (size_t)line0 * pitch;
     float* ob = out + (size_t)line0 * pitch;
     const int ntiles = (w + TS - 1) / TS;
