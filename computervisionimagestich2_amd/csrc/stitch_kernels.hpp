@@ -879,8 +879,10 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
     if (SRC && mk.enabled && (mk.h / TS) % 8 == 0) {
         // Source-fused level 0: the three channel sweeps of a band read the same index tiles.  Workgroups go round-robin
         // over the 8 XCDs (each with its own L2), so the planes of a pair are interleaved in groups of 8 bands: the seven
-        // blocks of one band are then 8 apart -- same XCD, dispatched together -- and the index tile is fetched from HBM
-        // once instead of three times.  (Plain order: plane-major, the channels of a band 64 blocks apart in time.)
+        // blocks of one band are then 8 apart -- same XCD, dispatched together -- so that a re-read of an index tile can
+        // be served on the chip.  (Plain order: plane-major, the channels of a band 64 blocks apart in time.)  Measured:
+        // the kernel is 1.5 % faster, but FETCH_SIZE (traffic leaving the L2) is unchanged -- at 8 workgroups per CU a
+        // 4 MB L2 does not keep a tile from one channel sweep to the next; what helps is the memory-side cache.
         const long nr = mk.h / TS, per_pair = 7 * nr, pr_ = blk / per_pair, r = blk % per_pair;
         const long band = (r / 56) * 8 + r % 8, q = (r / 8) % 7;
         blk = pr_ * per_pair + q * nr + band;
