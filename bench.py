@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- warp+blend MPix/s at 4096x4096x3 f32 (BASELINE.json), one process per GPU.
 
-A step = one pass of the hot path (warp + move + multi-band blend) over synthetic input: --streams (default 4)
-batches of --batch (default 8) independent config-2 pairs per rank (two 4096x4096x3 f32 frames -> 6144x4096x3 f32
-mosaic each; pair i of the config-4 family has p[3] = -2048 - 8i); a batch is ONE launch sequence of a batched plan
-on its own HIP stream.  Frames are generated on the device before the timed
-region, so every input is resident in HBM when timing starts.  Pairs are independent: each rank works on its own
-shard and there is NO data-path collective (weak scaling; RCCL carries only the barriers and the max-over-ranks of
-the step time).  --gather adds the optional assembly of SURVEY.md 8(e): each finished mosaic is cast to unsigned char
-(the reference's own output type) and all-gathered (RCCL over xGMI) on the communicator's stream while the next
-batch computes, so that every rank ends up holding the whole batch -- that exchange is then inside the timed region
-(at 8 GPUs it moves 5.4 GB per step into every rank and is link-bound, which is why it is not the default).
+Workload (the same at every N, so the N = 1, 2, 4, 8 lines are one strong-scaling curve): a STEP is one batch of
+--pairs-per-step (default 32) independent config-2 pairs -- BASELINE.json configs[3]: pair i = synthetic frames 2i+1
+(warped through the map with p[3] = -2048 - 8i) and 2i (the running mosaic), two 4096x4096x3 f32 frames ->
+6144x4096x3 f32 mosaic, warp + move + 12-level multi-band blend.  The batch is sharded contiguously over the ranks
+(pipeline.shard_range: 4 pairs per GPU on 8 ranks); a rank runs its shard as launch sequences of at most --batch (8)
+pairs on batched plans, up to --streams (4) sequences in flight on separate HIP streams, steps back to back with no
+host synchronisation between them.  Frames are generated on the device before the timed region: every input is
+resident in HBM when timing starts.
 
-Prints ONE JSON line (rank 0).  `value` comes from timed region 1 (all batches in flight).  `roofline` describes
-the dominant kernel (largest share of device time) in timed region 2, where one batch is in flight so that a
+N > 1: every finished mosaic is cast to unsigned char (the reference's own output type, CImg<unsigned char>) and the
+step's 32 mosaics are all-gathered (RCCL over xGMI, asynchronously, overlapping the next step's kernels) so that every
+rank ends up holding the whole batch -- the one exchange the path has, INSIDE the timed region; `value` includes it and
+`config.no_exchange_mpix_s` gives the same run without it.  N = 1: the rank already holds the batch, no exchange.
+
+Every timed region is checked: after it, status() of every plan and pair (seam scan + the fused sweep's sticky
+time-out count) and a bit-for-bit comparison of EVERY output buffer with the result of a separately created
+single-pair plan (the unfused launch sequence that tests/test_gpu_golden.py compares with the oracle at this size);
+N > 1 also checks the gathered blocks of all ranks by checksum.  `outputs_verified` reports it (all ranks).
+
+Prints ONE JSON line (rank 0).  `value` comes from timed region 1 (all sequences in flight).  `roofline` describes
+the dominant kernel (largest share of device time) in timed region 2, where one sequence is in flight so that a
 launch's duration is the kernel's own, timed with HIP events on the launch stream; `pipeline` gives the byte
-accounting for the whole pair at the `value` rate.  `cpu_baseline` (N=1, rank 0) times the oracle's CPU restatement on a bounded sample of the same workload.
+accounting for the whole pair at the `value` rate.  `cpu_baseline` (N=1, rank 0) times the oracle's CPU restatement
+on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -25,9 +34,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The HIP runtime multiplexes streams onto 4 hardware queues by default; batches that share a queue serialise behind each
-# other (4 streams on 4 queues, one of them shared with the default stream: 1.50 ms/pair; on 8 queues: 1.31).  Must be set
-# before the runtime initialises.
+# The HIP runtime multiplexes streams onto 4 hardware queues by default; sequences that share a queue serialise behind
+# each other (4 streams on 4 queues, one of them shared with the default stream: 1.50 ms/pair; on 8 queues: 1.31).  Must
+# be set before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E nominal, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
@@ -38,15 +47,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="independent pairs per batch (one launch sequence)")
-    ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU, each on its own HIP stream")
+    ap.add_argument("--pairs-per-step", type=int, default=32, help="pairs of one step over ALL ranks (32 = config 4's batch); "
+                    "--pairs-per-step 4 on one GPU rehearses one rank's share of the 8-GPU run")
+    ap.add_argument("--batch", type=int, default=8, help="pairs per launch sequence (batched plan), at most")
+    ap.add_argument("--streams", type=int, default=4, help="launch sequences in flight per GPU, each on its own HIP stream")
     ap.add_argument("--frame", type=int, default=4096, help="frame edge (4096 = the metric's configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frame", type=int, default=4096, help="frame edge of the CPU baseline's bounded sample")
     ap.add_argument("--no-kernel-events", action="store_true", help="time without per-launch HIP events")
     ap.add_argument("--pixel", choices=["f32", "u8"], default="f32", help="frame pixel type (f32 = the metric; u8 = the reference's own contract)")
     ap.add_argument("--no-single", action="store_true", help="skip the single-pair-in-flight latency measurement")
-    ap.add_argument("--gather", action="store_true", help="N>1: all-gather the finished uchar mosaics to every rank each step (inside the timed region)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: leave the finished mosaics on their ranks (no exchange at all)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the output comparison (status() checks stay)")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -114,11 +126,12 @@ def main():
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # STITCH_FORCE_DIST=1 runs the N>1 code path (RCCL init, quantise, asynchronous all-gather) with a single rank --
-    # a rehearsal of the multi-GPU path on a one-GPU box; it is never set by the driver
+    # STITCH_FORCE_DIST=1 runs the N>1 code path (RCCL init, quantise, asynchronous all-gather, all-reduces) with a single
+    # rank -- a rehearsal of the multi-GPU path on a one-GPU box; it is never set by the driver
     force_dist = world == 1 and os.environ.get("STITCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
-    use_gather = force_dist or (world > 1 and args.gather)
+    use_gather = use_dist and not args.no_gather
+    n_ranks_seen = 1
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with _StdoutToStderr():
@@ -128,72 +141,92 @@ def main():
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
             else:
                 dist.init_process_group("nccl", device_id=dev)
-            dist.barrier()  # creates the communicator now (and its banner), not inside the timed region
+            # a real collective over the communicator (creates it now, banner included, not inside the timed region):
+            # every rank contributes 1, so the sum is the number of ranks RCCL actually connected
+            ones = torch.ones(1, dtype=torch.int32, device=dev)
+            dist.all_reduce(ones)
             torch.cuda.synchronize()
+            n_ranks_seen = int(ones.item())
+        if n_ranks_seen != dist.get_world_size():
+            raise SystemExit(f"RCCL saw {n_ranks_seen} ranks, world size is {dist.get_world_size()}")
 
     F = args.frame
     cw, ch = pipeline.config_canvas(F)
-    K, W, B, S = args.steps, args.warmup, args.batch, args.streams
+    K, W, P = args.steps, args.warmup, args.pairs_per_step
+    if P < world:
+        raise SystemExit(f"--pairs-per-step {P} < {world} ranks")
     tdt = torch.float32 if args.pixel == "f32" else torch.uint8
     px_bytes = 4 if args.pixel == "f32" else 1
 
-    # S "lanes": each lane = one batched plan (B pairs per launch sequence) on its own HIP stream, so that the
-    # latency-bound small pyramid levels of one batch overlap the bandwidth-bound sweeps of the other.
-    # Inputs: this rank's pairs come from the config-4 family (frames 2i, 2i+1; map p[3] = -F/2 - 8i); a few distinct
-    # batches per lane are cycled; everything is resident in HBM before timing starts.
-    n_distinct = 2
-    first = rank * K * B * S
+    # ---- this rank's shard of the step, as launch sequences ------------------------------------------------------
+    lo, hi = pipeline.shard_range(P, rank, world)
+    n_local = hi - lo
+    n_max = pipeline.shard_range(P, 0, world)[1]  # the largest shard (rank 0's): equal blocks for the all-gather
+    B = min(args.batch, n_local)
+    seqs = pipeline.batches_of(P, rank, world, B)  # [(first, last+1)] global pair indices, one launch sequence each
+    nb = len(seqs)
+    S = max(1, min(args.streams, nb * max(K, 1)))
+    pair_in = {}
+    for i in range(lo, hi):
+        pair_in[i] = (capi.dev_synth(F, F, 2 * i + 1, tdt, dev), pipeline.config_map(i, F), 0.0, 0.0,
+                      capi.dev_synth(F, F, 2 * i, tdt, dev), 0, 0)
     lanes = []
     for ln in range(S):
-        batches = []
-        for j in range(n_distinct):
-            items = []
-            for q in range(B):
-                i = (first + (ln * n_distinct + j) * B + q) % 32
-                items.append((capi.dev_synth(F, F, 2 * i + 1, tdt, dev), pipeline.config_map(i, F), 0.0, 0.0,
-                              capi.dev_synth(F, F, 2 * i, tdt, dev), 0, 0))
-            batches.append(items)
-        lanes.append({
-            "plan": capi.Plan(cw, ch, max_pairs=B),
-            "stream": torch.cuda.Stream(device=dev),
-            "batches": batches,
-            "outs": [[torch.empty((3, ch, cw), dtype=tdt, device=dev) for _ in range(B)] for _ in range(2)],
-            # N>1: finished mosaics travel as unsigned char (the reference's output type) through pipeline.MosaicGather
-            # -- the class the gloo tests cover -- asynchronously: the gather of step k overlaps the kernels of step k+1
-            "gather": pipeline.MosaicGather((B, 3, ch, cw), dev, world, rank, slots=2, force_collective=force_dist) if use_gather else None,
-        })
+        lanes.append({"plan": capi.Plan(cw, ch, max_pairs=B), "stream": torch.cuda.Stream(device=dev),
+                      "outs": [[torch.empty((3, ch, cw), dtype=tdt, device=dev) for _ in range(B)] for _ in range(2)],
+                      "holds": [None, None], "last": None})
     plan = lanes[0]["plan"]
+    gather = None
+    if use_gather:
+        # finished mosaics travel as unsigned char through pipeline.MosaicGather -- the class the gloo tests cover; one block
+        # of n_max mosaics per rank and step, two steps of buffers so that the gather of step k overlaps the kernels of k+1
+        gather = pipeline.MosaicGather((n_max, 3, ch, cw), dev, world, rank, slots=2, force_collective=True)
+        gstream = torch.cuda.Stream(device=dev)
 
-    def lane_step(ln, k, n=B):
+    def run_seq(c, seq, gather_step=None, n=None):
+        """Launch sequence number c (a global counter picks lane and output slot) over global pairs seq = (first, last+1)."""
+        ln, slot = c % S, (c // S) % 2
         L = lanes[ln]
+        idx = list(range(seq[0], seq[1]))[:n]
         with torch.cuda.stream(L["stream"]):
-            outs = L["outs"][k % 2]
-            L["plan"].pairs([it + (outs[q],) for q, it in enumerate(L["batches"][k % n_distinct][:n])])
-            if L["gather"] is not None:
-                slot = L["gather"].input_slot(k)
-                for q in range(n):
+            outs = L["outs"][slot]
+            L["plan"].pairs([pair_in[i] + (outs[q],) for q, i in enumerate(idx)])
+            L["holds"][slot] = idx
+            L["last"] = slot
+            if gather_step is not None:
+                blk = gather.input_slot(gather_step)  # waits (on this stream) for the gather that last used the buffers
+                for q, i in enumerate(idx):
                     if tdt == torch.float32:
-                        capi.dev_quantize(outs[q], slot[q])
+                        capi.dev_quantize(outs[q], blk[i - lo])
                     else:
-                        slot[q].copy_(outs[q])
-                L["gather"].submit(k)
+                        blk[i - lo].copy_(outs[q])
+                ev = torch.cuda.Event()
+                ev.record(L["stream"])
+                return ev
+        return None
+
+    def step(k, with_gather):
+        evs = [run_seq(k * nb + j, seqs[j], k if with_gather else None) for j in range(nb)]
+        if with_gather:
+            with torch.cuda.stream(gstream):
+                for ev in evs:
+                    gstream.wait_event(ev)
+                gather.submit(k)  # asynchronous: runs on RCCL's stream behind gstream
 
     def drain():
-        for L in lanes:
-            if L["gather"] is not None:
-                with torch.cuda.stream(L["stream"]):
-                    L["gather"].drain()
+        if gather is not None:
+            with torch.cuda.stream(gstream):
+                gather.drain()
         torch.cuda.synchronize()
 
-    def timed(n_lanes, steps, k0):
-        """steps x (one batch on each of n_lanes lanes), bracketed by barrier + synchronize; max over ranks."""
+    def timed(fn, steps):
+        """`steps` x fn(k), bracketed by barrier + synchronize on both sides; max over ranks."""
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(steps):
-            for ln in range(n_lanes):
-                lane_step(ln, k0 + k)
+            fn(k)
         drain()
         if use_dist:
             dist.barrier()
@@ -205,78 +238,150 @@ def main():
             el = float(t.item())
         return el
 
-    for k in range(W):
-        for ln in range(S):
-            lane_step(ln, k)
-    drain()
-    for L in lanes:
-        for q in range(B):
-            L["plan"].status(q)  # raises if a seam scan failed
+    # ---- reference results for the output check: every local pair through a single-pair plan (unfused sweeps, plain
+    # launch sequence; compared with the oracle at this very size by tests/test_gpu_golden.py) ------------------------
+    ref_out, ref_q = {}, {}
+    if not args.no_verify:
+        one = capi.Plan(cw, ch)
+        for i in range(lo, hi):
+            ref_out[i] = one.pair(pair_in[i][0], pair_in[i][1], 0.0, 0.0, pair_in[i][4], 0, 0)
+            one.status()
+            if use_gather:
+                q8 = capi.dev_quantize(ref_out[i]) if tdt == torch.float32 else ref_out[i]
+                ref_q[i] = int(q8.view(torch.int32).sum(dtype=torch.int64).item()) if q8.numel() % 4 == 0 else int(q8.sum(dtype=torch.int64).item())
+        one.close()
+    checks = {"regions": 0, "buffers": 0, "bad": []}
 
-    # pilot (one lane, every launch bracketed by HIP events; ~10 % overhead, so never the timed region): per-kernel
+    def verify(tag, gather_step=None):
+        """After a timed region: status of every plan and pair, every output buffer against its reference."""
+        torch.cuda.synchronize()
+        for ln, L in enumerate(lanes):
+            if L["last"] is None:
+                continue
+            try:
+                for q in range(len(L["holds"][L["last"]])):
+                    L["plan"].status(q)  # raises on a failed seam scan or a timed-out hand-off in ANY queued call
+            except capi.StitchError as e:
+                checks["bad"].append(f"{tag}: lane {ln}: {e}")
+                L["plan"].clear_fault()
+            if args.no_verify:
+                continue
+            for slot in range(2):
+                for q, i in enumerate(L["holds"][slot] or []):
+                    checks["buffers"] += 1
+                    if not torch.equal(L["outs"][slot][q], ref_out[i]):
+                        checks["bad"].append(f"{tag}: lane {ln} slot {slot} pair {i} differs from the single-pair plan")
+        if gather_step is not None and not args.no_verify:
+            # the gathered batch of the last step: this rank's own checksums travel by all-gather, every block is checked
+            mine = torch.tensor([ref_q.get(lo + j, 0) for j in range(n_max)], dtype=torch.int64, device=dev)
+            allq = torch.empty(world * n_max, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allq, mine)
+            got = gather.out[gather_step % 2]
+            for r in range(world):
+                rlo, rhi = pipeline.shard_range(P, r, world)
+                for j in range(rhi - rlo):
+                    blk = got[r][j]
+                    s_ = int(blk.view(torch.int32).sum(dtype=torch.int64).item()) if blk.numel() % 4 == 0 else int(blk.sum(dtype=torch.int64).item())
+                    checks["buffers"] += 1
+                    if s_ != int(allq[r * n_max + j].item()):
+                        checks["bad"].append(f"{tag}: gathered mosaic of rank {r}, pair {rlo + j}: checksum differs")
+        checks["regions"] += 1
+
+    # ---- warm-up ---------------------------------------------------------------------------------------------------
+    for k in range(W):
+        step(k, use_gather)
+    drain()
+    verify("warm-up", (W - 1) if (use_gather and W > 0) else None)
+
+    # pilot (lane 0, every launch bracketed by HIP events; ~10 % overhead, so never the timed region): per-kernel
     # table and the choice of the dominant kernel
     plan.set_profiling(True)
     plan.read_profile()
     PILOT = 3
     for k in range(PILOT):
-        lane_step(0, W + k)
-    drain()
+        run_seq(k * S, seqs[0])
+    torch.cuda.synchronize()
     pilot = plan.read_profile()
     dom = max(pilot, key=lambda k_: pilot[k_][0])
     plan.set_profiling(False)
 
-    # timed region 1 -> `value`: all S lanes in flight
-    elapsed = timed(S, K, W + PILOT)
+    # timed region 1 -> `value`: every launch sequence of K steps in flight over S streams (+ the exchange, N > 1)
+    elapsed = timed(lambda k: step(k, use_gather), K)
+    verify("region 1", (K - 1) if use_gather else None)
+    elapsed_noex = None
+    if use_gather:
+        elapsed_noex = timed(lambda k: step(k, False), K)
+        verify("region 1 (no exchange)")
 
-    # timed region 2 -> `roofline`: ONE lane in flight (kernels do not overlap, so a launch's duration is the kernel's
+    # timed region 2 -> `roofline`: ONE sequence in flight (kernels do not overlap, so a launch's duration is the kernel's
     # own), HIP events around the dominant kernel's launches only, on the launch stream
     if not args.no_kernel_events:
         plan.set_profiling_kernel(dom)
     plan.read_profile()
-    elapsed_one = timed(1, K, W + PILOT + K)
+    elapsed_one = timed(lambda k: run_seq(k * S, seqs[0]), K)
     prof = plan.read_profile()
     plan.set_profiling(False)
+    verify("region 2")
     seam = plan.status(0)
+    n_seq0 = seqs[0][1] - seqs[0][0]
 
     # single pair in flight (config 2 as a latency figure)
     single_ms = None
     if world == 1 and not args.no_single:
         for k in range(2):
-            lane_step(0, k, 1)
+            run_seq(k * S, seqs[0], n=1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for k in range(5):
-            lane_step(0, k, 1)
+            run_seq(k * S, seqs[0], n=1)
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / 5 * 1e3
 
+    ok = torch.tensor([0 if checks["bad"] else 1], dtype=torch.int32, device=dev)
+    if use_dist:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    verified = bool(ok.item()) and not args.no_verify
+    for msg in checks["bad"]:
+        print(f"[bench] rank {rank}: OUTPUT CHECK FAILED: {msg}", file=sys.stderr)
+
     if rank == 0:
         mpix_pair = cw * ch / 1e6
-        value = mpix_pair * K * B * S * world / elapsed
-        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, px_bytes, plan.fused_sweep_levels)
+        value = mpix_pair * K * P / elapsed
+        src_fused = ch % 64 == 0 and os.environ.get("STITCH_NO_SRC_FUSE") is None and os.environ.get("STITCH_NO_FUSE") is None
+        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, px_bytes, plan.fused_sweep_levels,
+                                                        fused_decimate=os.environ.get("STITCH_NO_FUSE") is None, source_fused=src_fused,
+                                                        implicit_mask=src_fused)
         line = {
             "metric": "warp+blend MPix/s at 4096x4096x3 f32" if args.pixel == "f32" else "warp+blend MPix/s at 4096x4096x3 u8", "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 (f64 accumulators)" if args.pixel == "f32" else "u8 frames, f32 pyramids (f64 accumulators)",
-            "data": "synthetic",
+            "data": "synthetic", "outputs_verified": verified, "n_ranks_seen": n_ranks_seen,
             "config": {"workload": f"config 2 pairs ({F}x{F}x3 {args.pixel} frames -> {cw}x{ch}x3 {args.pixel} mosaic: warp + move + "
-                                   f"{plan.levels}-level multi-band blend); per GPU per step {S} batches of {B} independent pairs, "
-                                   f"each batch one launch sequence on its own HIP stream (config 4's per-GPU shard); canvas pixels counted",
-                       "frame": [F, F, 3], "canvas": [cw, ch, 3], "levels": plan.levels, "pairs_per_batch": B,
-                       "batches_in_flight": S, "fused_sweep_levels": plan.fused_sweep_levels, "pairs_per_step": B * S * world, "mpix_per_pair": round(mpix_pair, 3),
-                       "ms_per_pair_per_gpu": round(elapsed / K / B / S * 1e3, 4),
-                       "one_batch_in_flight_ms_per_pair": round(elapsed_one / K / B * 1e3, 4),
-                       "one_batch_in_flight_mpix_s": round(mpix_pair * K * B * world / elapsed_one, 1),
+                                   f"{plan.levels}-level multi-band blend), {P} independent pairs per step (config 4's batch) sharded contiguously "
+                                   f"over {world} rank(s): {n_local} pairs per rank per step as {nb} launch sequence(s) of {B} on batched plans, "
+                                   f"{S} sequences in flight per GPU on separate HIP streams; canvas pixels counted",
+                       "frame": [F, F, 3], "canvas": [cw, ch, 3], "levels": plan.levels, "pairs_per_step": P, "pairs_per_rank_per_step": n_local,
+                       "pairs_per_sequence": B, "sequences_in_flight": S, "fused_sweep_levels": plan.fused_sweep_levels,
+                       "mpix_per_pair": round(mpix_pair, 3),
+                       "ms_per_pair_per_gpu": round(elapsed / K / n_local * 1e3, 4),
+                       "one_sequence_in_flight_ms_per_pair": round(elapsed_one / K / n_seq0 * 1e3, 4),
+                       "one_sequence_in_flight_mpix_s": round(mpix_pair * K * n_seq0 / elapsed_one, 1),
                        "single_pair_in_flight_ms": round(single_ms, 4) if single_ms else None,
                        "single_pair_in_flight_mpix_s": round(mpix_pair / single_ms * 1e3, 1) if single_ms else None,
-                       "input_frame_mpix_per_s": round(2 * F * F / 1e6 * K * B * S * world / elapsed, 2),
-                       "exchange": "uint8 mosaics all-gathered (RCCL) overlapped with compute" if use_gather else "none (independent shards; RCCL for barriers and timing only)",
+                       "input_frame_mpix_per_s": round(2 * F * F / 1e6 * K * P / elapsed, 2),
+                       "exchange": (f"every step's {P} finished mosaics cast to uint8 and all-gathered (RCCL, asynchronous, overlapping the "
+                                    f"next step) inside the timed region: {n_max * 3 * ch * cw * (world - 1) / 1e9:.2f} GB into every rank per step")
+                                   if use_gather else "none (one rank holds the whole batch)" if world == 1 else "none (--no-gather)",
+                       "no_exchange_mpix_s": round(mpix_pair * K * P / elapsed_noex, 2) if elapsed_noex else None,
+                       "output_check": {"timed_regions_checked": checks["regions"], "buffers_compared": checks["buffers"],
+                                        "against": "single-pair plan (separate launch sequence), bit for bit; status() of every plan and pair",
+                                        "failures": len(checks["bad"])},
                        "seam": list(seam.as_tuple())},
         }
         if prof[dom][1] > 0:
             ms, launches, _ = prof[dom]
-            bytes_per_launch = per_kernel[dom] * B * K / launches  # region 2: K steps of one batch of B pairs
+            bytes_per_launch = per_kernel[dom] * n_seq0 * K / launches  # region 2: K launch sequences of n_seq0 pairs
             avg_s = ms / launches / 1e3
             achieved = bytes_per_launch / avg_s / 1e9
             traffic = None
@@ -284,7 +389,7 @@ def main():
             if os.path.exists(tpath):
                 try:
                     te = json.load(open(tpath)).get(dom, {})
-                    traffic = te.get("hbm_bytes_per_launch") if te.get("batch") == B and F == 4096 else None
+                    traffic = te.get("hbm_bytes_per_launch") if te.get("batch") == n_seq0 and F == 4096 else None
                 except Exception:
                     traffic = None
             pilot_tot = sum(v[0] for v in pilot.values())
@@ -307,30 +412,32 @@ def main():
                                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                                 "share_of_device_time": round(pilot[dom][0] / pilot_tot, 4),
                                 "device_copy_GBps": round(copy_gbs, 1),
-                                "note": "timed region 2 (one batch in flight, so launches of different batches do not overlap): average over "
-                                        "every launch of this kernel symbol (all pyramid levels); HIP events on the launch stream"}
-        line["kernels"] = {k_: {"ms_per_pair": round(v[0] / PILOT / B, 4), "launches_per_step": v[1] // PILOT,
-                                "level0_ms_per_pair": round(v[2] / PILOT / B, 4),
-                                "algorithmic_GBps": round(per_kernel[k_] / (v[0] / PILOT / B / 1e3) / 1e9, 1) if v[0] > 0 else None}
-                           for k_, v in pilot.items()}
-        pair_s = elapsed / K / B / S
+                                "note": "timed region 2 (one launch sequence in flight, so launches do not overlap): average over every launch of "
+                                        "this kernel symbol (all pyramid levels); HIP events on the launch stream; bytes = what this kernel "
+                                        "itself reads and writes once (pipeline.algorithmic_bytes, fusion taken into account)"}
+            kern = {}
+            for k_, v in pilot.items():
+                gbps = per_kernel[k_] / (v[0] / PILOT / n_seq0 / 1e3) / 1e9 if v[0] > 0 else None
+                kern[k_] = {"ms_per_pair": round(v[0] / PILOT / n_seq0, 4), "launches_per_sequence": v[1] // PILOT,
+                            "level0_ms_per_pair": round(v[2] / PILOT / n_seq0, 4), "owned_bytes_per_pair": per_kernel[k_],
+                            "algorithmic_GBps": round(gbps, 1) if gbps is not None else None}
+                if gbps is not None and gbps > copy_gbs * 1.6:  # sanity: nothing streams far above the box's own copy rate
+                    kern[k_]["suspect"] = "above the device copy rate: byte accounting or timing is off"
+            line["kernels"] = kern
+        pair_s = elapsed / K / P
         line["pipeline"] = {"algorithmic_bytes_per_pair": stages["total"], "S1": stages["S1"], "S2": stages["S2"], "S3": stages["S3"],
-                            "achieved_GBps_per_gpu": round(stages["total"] / pair_s / 1e9, 1),
-                            "frac_of_hbm_peak": round(stages["total"] / pair_s / 1e9 / HBM_PEAK_GBS, 4)}
+                            "achieved_GBps_per_gpu": round(stages["total"] / pair_s / 1e9 / world, 1),
+                            "frac_of_hbm_peak": round(stages["total"] / pair_s / 1e9 / world / HBM_PEAK_GBS, 4),
+                            "owned_bytes_per_pair_all_kernels": sum(per_kernel.values())}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_frame, args.verbose)
         print(json.dumps(line), flush=True)
-    if use_gather and rank == 0 and os.environ.get("STITCH_CHECK_GATHER") == "1":
-        # rehearsal check: the last gathered block of lane 0 holds this rank's own quantised mosaics
-        L = lanes[0]
-        last = W + PILOT + 2 * K - 1
-        own = L["gather"].out[last % 2][rank]
-        ok = all(torch.equal(own[q], capi.dev_quantize(L["outs"][last % 2][q]) if tdt == torch.float32 else L["outs"][last % 2][q]) for q in range(B))
-        print(f"[gather check] own mosaics in the gathered block: {'ok' if ok else 'MISMATCH'}", file=sys.stderr)
     for L in lanes:
         L["plan"].close()
     if use_dist:
         dist.destroy_process_group()
+    if checks["bad"] and not args.no_verify:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -491,6 +491,13 @@ class Plan:
         _chk(lib().stitch_plan_status_at(self._h, int(index), C.byref(s)))
         return s
 
+    def clear_fault(self):
+        """Acknowledge the fused sweep's sticky time-out report (stitch_plan_clear_fault)."""
+        _chk(lib().stitch_plan_clear_fault(self._h))
+
+    def set_handoff_spin_limit(self, polls):
+        _chk(lib().stitch_plan_set_handoff_spin_limit(self._h, C.c_uint(int(polls))))
+
     def set_profiling_kernel(self, name):
         _chk(lib().stitch_plan_set_profiling_kernel(self._h, KERNELS.index(name)))
 

@@ -167,6 +167,7 @@ struct Level {
 };
 
 constexpr int WF_CTRL_WORDS = 4 * 16 + 16;  // band-queue heads of up to 4 levels (64 bytes apart) + the abort word
+constexpr int WF_STICKY_WORDS = 16;         // behind them, outside what a launch sequence clears: the plan's count of timed-out waits
 
 struct ProfRec {
     int stage, level;
@@ -196,9 +197,13 @@ struct stitch_plan {
     uint8_t* zt = nullptr;         // zero-tile flags of T, [7*cap][bands][tiles] of level 0 (ZeroTiles); reused level by level
     bool zero_tiles = false;
     int wf_max_wgs = 2304;  // persistent workgroups of the fused sweep (STITCH_XBYF_WGS)
+    unsigned wf_spin_limit = 1u << 20;  // polls before a hand-off wait gives up (STITCH_XBYF_SPIN_LIMIT)
     int wf_early_read = 1;  // STITCH_XBYF_EARLY=0: poll for the hand-off only when it is needed
-    unsigned long long* wf_dbg = nullptr;  // STITCH_WAVEFRONT_STAMP=1: [2048][8] segment cycle sums (diagnostics)
-    unsigned* h_wf_abort = nullptr;  // pinned copy of the abort flag of the last call
+    unsigned long long* wf_dbg = nullptr;  // STITCH_WAVEFRONT_STAMP=1: [wf_max_wgs][8] segment cycle sums (diagnostics)
+    // pinned copy of the plan's sticky count of timed-out hand-off waits, refreshed at the end of every call.  The device
+    // word only grows (no launch sequence clears it), so the last copy covers every earlier queued call as well.
+    unsigned* h_wf_abort = nullptr;
+    unsigned wf_abort_seen = 0;  // count already acknowledged by stitch_plan_clear_fault
     float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
     bool mask_opt = false;  // level-0 mask handled implicitly (Van Vliet, level-0 height a multiple of 64)
     int crows_ln = 4 * CROWS;  // rows per strip of the collapse at levels >= 1 (STITCH_CROWS_LN): slower alone than 8, fewer bytes with other batches in flight
@@ -296,6 +301,8 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             wf.yg = p->wf_yg;
             wf.counter = p->wf_ctrl + (size_t)l * 16;
             wf.abort = p->wf_ctrl + WF_CTRL_WORDS - 16;
+            wf.sticky = p->wf_ctrl + WF_CTRL_WORDS;
+            wf.spin_limit = p->wf_spin_limit;
             wf.NR = (a.h + TS - 1) / TS;
             wf.NC = (a.w + TS - 1) / TS;
             wf.NP = np;
@@ -372,7 +379,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             k_decimate<<<grid_xy(b.pitch, b.h, np), 256, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, b.g, b.w, b.h, b.pitch, b.ps);
         }
     }
-    if (p->wf_levels > 0) HIPCHK(hipMemcpyAsync(p->h_wf_abort, p->wf_ctrl + WF_CTRL_WORDS - 16, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    if (p->wf_levels > 0) HIPCHK(hipMemcpyAsync(p->h_wf_abort, p->wf_ctrl + WF_CTRL_WORDS, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     return launch_check("reduce");
 }
 
@@ -915,7 +922,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     while (wf_levels > 0 && (lw[wf_levels - 1] < 2 || lh[wf_levels - 1] < 2)) --wf_levels;
     const int NC0 = (v0.w + TS - 1) / TS;
     const size_t yg_off = wf_levels ? take(sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE) : 0;
-    const size_t wfc_off = wf_levels ? take(sizeof(unsigned) * WF_CTRL_WORDS) : 0;
+    const size_t wfc_off = wf_levels ? take(sizeof(unsigned) * (WF_CTRL_WORDS + WF_STICKY_WORDS)) : 0;
     const size_t zi_off = take((size_t)B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS));
     const size_t zt_off = wf_levels ? take((size_t)7 * B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS)) : 0;
     // x-sweep state [4][lines] followed by the y state the wavefront kernel leaves [4][planes][pitch]
@@ -946,16 +953,21 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     p->state = reinterpret_cast<double*>(base + st_off);
     p->d_seam = reinterpret_cast<SeamDev*>(base + seam_off);
     p->wf_levels = wf_levels;
-    if (wf_levels && std::getenv("STITCH_WAVEFRONT_STAMP")) {
-        if (hipMalloc((void**)&p->wf_dbg, sizeof(unsigned long long) * 2304 * 8) != hipSuccess) p->wf_dbg = nullptr;
-    }
     if (wf_levels) {
         p->wf_yg = reinterpret_cast<u64*>(base + yg_off);
         p->wf_yg_bytes = sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE;
         p->wf_ctrl = reinterpret_cast<unsigned*>(base + wfc_off);
         p->zt = reinterpret_cast<uint8_t*>(base + zt_off);
         p->zi = reinterpret_cast<uint8_t*>(base + zi_off);
-        if (const char* ew = std::getenv("STITCH_XBYF_WGS")) p->wf_max_wgs = std::max(64, atoi(ew));
+        if (const char* ew = std::getenv("STITCH_XBYF_WGS")) p->wf_max_wgs = std::max(1, atoi(ew));
+        if (const char* es = std::getenv("STITCH_XBYF_SPIN_LIMIT")) p->wf_spin_limit = (unsigned)std::max(0, atoi(es));
+        // diagnostic build: one record per persistent workgroup, sized from the workgroup count actually used
+        if (std::getenv("STITCH_WAVEFRONT_STAMP") &&
+            (hipMalloc((void**)&p->wf_dbg, sizeof(unsigned long long) * (size_t)p->wf_max_wgs * 8) != hipSuccess ||
+             hipMemset(p->wf_dbg, 0, sizeof(unsigned long long) * (size_t)p->wf_max_wgs * 8) != hipSuccess)) {
+            (void)hipGetLastError();
+            p->wf_dbg = nullptr;
+        }
         if (const char* ee = std::getenv("STITCH_XBYF_EARLY")) p->wf_early_read = atoi(ee) != 0;
         const char* ez = std::getenv("STITCH_NO_ZERO_TILES");  // A/B and tests: move the zeros like any other sample
         p->zero_tiles = !(ez && atoi(ez) != 0);
@@ -1014,17 +1026,18 @@ void stitch_plan_destroy(stitch_plan* p) {
     if (p->h_seam) (void)hipHostFree(p->h_seam);
     if (p->h_wf_abort) (void)hipHostFree(p->h_wf_abort);
     if (p->wf_dbg) {
-        std::vector<unsigned long long> hsum(2304 * 8);
-        if (hipMemcpy(hsum.data(), p->wf_dbg, sizeof(unsigned long long) * 2304 * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+        const size_t nwg = (size_t)p->wf_max_wgs;
+        std::vector<unsigned long long> hsum(nwg * 8);
+        if (hipMemcpy(hsum.data(), p->wf_dbg, sizeof(unsigned long long) * nwg * 8, hipMemcpyDeviceToHost) == hipSuccess) {
             double tot[8] = {0};
-            for (int i = 0; i < 2304; ++i)
+            for (size_t i = 0; i < nwg; ++i)
                 for (int j = 0; j < 8; ++j) tot[j] += (double)hsum[i * 8 + j];
             static const char* nm[8] = {"claim", "tile-fetch", "x-sweep", "y-wait", "y-sweep", "store", "-", "-"};
             double all = 0;
             for (int j = 0; j < 6; ++j) all += tot[j];
             std::fprintf(stderr, "[wavefront stamps, last level-0 launch, share of workgroup time]");
             for (int j = 0; j < 6; ++j) std::fprintf(stderr, " %s %.1f%%", nm[j], 100.0 * tot[j] / all);
-            std::fprintf(stderr, " | mean cycles per workgroup %.0f\n", all / 2304);
+            std::fprintf(stderr, " | mean cycles per workgroup %.0f\n", all / (double)nwg);
         }
         (void)hipFree(p->wf_dbg);
     }
@@ -1064,7 +1077,11 @@ int stitch_plan_status_at(stitch_plan* p, int index, stitch_seam* seam_out) {
         HIPCHK(hipStreamSynchronize(p->last_stream));
         p->pending = false;
     }
-    if (p->h_wf_abort && *p->h_wf_abort) return fail(STITCH_ERR_HIP, "wavefront sweep timed out waiting for a neighbouring tile (results are invalid)");
+    if (p->h_wf_abort && *p->h_wf_abort != p->wf_abort_seen)
+        return fail(STITCH_ERR_HIP,
+                    "fused sweep: %u hand-off wait(s) timed out in this or an earlier queued call on the plan (every result since the "
+                    "last stitch_plan_clear_fault is invalid)",
+                    *p->h_wf_abort - p->wf_abort_seen);
     const SeamDev& sd = p->h_seam[index];
     seam_to_public(sd, seam_out);
     if (sd.status == -2) return fail(STITCH_ERR_EMPTY_MIDROW, "blend: channel 0 of a's middle row is empty (pair %d)", index);
@@ -1073,6 +1090,22 @@ int stitch_plan_status_at(stitch_plan* p, int index, stitch_seam* seam_out) {
 }
 
 int stitch_plan_status(stitch_plan* p, stitch_seam* seam_out) { return stitch_plan_status_at(p, 0, seam_out); }
+
+int stitch_plan_set_handoff_spin_limit(stitch_plan* p, unsigned polls) {
+    if (!p) return fail(STITCH_ERR_ARG, "null plan");
+    p->wf_spin_limit = polls;
+    return STITCH_OK;
+}
+
+int stitch_plan_clear_fault(stitch_plan* p) {
+    if (!p) return fail(STITCH_ERR_ARG, "null plan");
+    if (p->pending) {
+        HIPCHK(hipStreamSynchronize(p->last_stream));
+        p->pending = false;
+    }
+    if (p->h_wf_abort) p->wf_abort_seen = *p->h_wf_abort;
+    return STITCH_OK;
+}
 
 int stitch_plan_capacity(const stitch_plan* p) { return p ? p->cap : 0; }
 int stitch_plan_fused_sweep_levels(const stitch_plan* p) { return p ? p->wf_levels : 0; }

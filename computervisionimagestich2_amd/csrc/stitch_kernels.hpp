@@ -1437,9 +1437,12 @@ struct Wavefront {
     u64* yg;            // [planes][NC][7][64] granules: y state leaving band R towards band R+1 (+ one spare word)
     int mask_l0;        // level-0 implicit mask (see MaskL0): planes p%7==6 carry their x-blurred row in the 7th granule
     unsigned* counter;  // band queue head (zeroed by the host before the launch)
-    unsigned* abort;    // set when a spin timed out
+    unsigned* abort;    // set when a spin timed out (cleared in front of every launch sequence)
+    unsigned* sticky;   // count of timed-out waits since the plan was created: NEVER cleared by the launch sequence, so
+                        // a bail-out in any earlier queued call is still visible to stitch_plan_status_at
     int NR, NC, NP;
     unsigned epoch;
+    unsigned spin_limit;      // polls before a wait gives up (STITCH_XBYF_SPIN_LIMIT; tests force the bail-out path with 0)
     ZeroTiles zt;             // zero-tile flags of T at this level (see ZeroTiles)
     int early_read;           // read the hand-off state ahead of the tile prefetch (granules_issue)
     unsigned long long* dbg;  // diagnostic build only: [workgroups][8] cycle sums per segment
@@ -1481,8 +1484,8 @@ __device__ __forceinline__ bool granules_accept(const u64 g[WF_GRAN], unsigned t
     c = __longlong_as_double((long long)((g[4] & 0xffffffffu) | (g[5] << 32)));
     return true;
 }
-__device__ __forceinline__ bool granules_consume(const u64* base, int lane, unsigned tag, unsigned* abort, double& a, double& b,
-                                                 double& c, unsigned& extra) {
+__device__ __forceinline__ bool granules_consume(const u64* base, int lane, unsigned tag, unsigned* abort, unsigned* sticky,
+                                                 unsigned spin_limit, double& a, double& b, double& c, unsigned& extra) {
     for (unsigned spins = 0;; ++spins) {
         // two-phase poll: one lane watches the tag of one granule, the whole wavefront reads the seven only once it has
         // appeared (polling all seven, or sleeping less, measured within +-3 %)
@@ -1511,8 +1514,11 @@ __device__ __forceinline__ bool granules_consume(const u64* base, int lane, unsi
                 unsigned ab = 0;
                 if (lane == 0) ab = __hip_atomic_load((gu32*)abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ab = __shfl(ab, 0, 64);
-                if (ab != 0 || spins > (1u << 20)) {
-                    if (lane == 0) __hip_atomic_store((gu32*)abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ab != 0 || spins > spin_limit) {
+                    if (lane == 0) {
+                        __hip_atomic_store((gu32*)abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        atomicAdd(sticky, 1u);
+                    }
                     return false;
                 }
             }
@@ -1650,7 +1656,7 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             } else {
                 const bool hit = early_on && granules_accept(early, (wf.epoch << 12) | (unsigned)R, u1, u2, u3, rowbits);
                 if (early_on) spec = hit;
-                if (!hit && !granules_consume(slot, lane, (wf.epoch << 12) | (unsigned)R, wf.abort, u1, u2, u3, rowbits)) {
+                if (!hit && !granules_consume(slot, lane, (wf.epoch << 12) | (unsigned)R, wf.abort, wf.sticky, wf.spin_limit, u1, u2, u3, rowbits)) {
                     dead = true;
                     break;
                 }

@@ -30,44 +30,65 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample=4, fused_sweep_levels=0):
+def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample=4, fused_sweep_levels=0, fused_decimate=True,
+                      source_fused=False, implicit_mask=False):
     """SURVEY.md 8(d) byte accounting for one pair: every distinct input array read once + every output array
-    written once, pyramid planes f32.  Returns per-kernel bytes (this implementation's kernels, each with its own
-    inputs/outputs counted once) and the canonical stage totals S1..S3 the headline fraction uses."""
+    written once, pyramid planes f32.  Returns (per_kernel, stages): `stages` are the canonical totals S1..S3 the
+    headline fraction uses (independent of how the kernels are fused); `per_kernel` gives each of THIS implementation's
+    kernels the bytes it actually owns -- its own inputs read once and its own outputs written once, given the fusion
+    the plan runs with -- so that no kernel is credited traffic another kernel (or nobody) moves:
+      fused_decimate   k_vv_y_bwd_dec reads level l and writes only level l+1 (the blurred level is never stored)
+      fused_sweep_levels  levels whose anticausal-x and causal-y sweeps are one kernel (k_vv_xbyf: one R + one W)
+      source_fused     level 0 is never materialised: k_src_index writes one 4-byte index plane; the causal x sweep and the
+                       level-0 collapse read the frames (through that plane) instead of six level-0 planes
+      implicit_mask    the level-0 mask plane is never read (a step function of x); the fused sweep still writes its blur"""
     n = [w * h for w, h in zip(level_w, level_h)]
     L = len(n)
     P = n[0]
-    s1 = (frame_px_a + frame_px_b) * 3 * bytes_per_sample + 2 * P * 3 * 4
+    inputs = (frame_px_a + frame_px_b) * 3 * bytes_per_sample
+    s1 = inputs + 2 * P * 3 * 4
     s2 = sum(7 * 4 * (3 * n[l] + n[l + 1]) for l in range(L - 1))
     s3 = sum(4 * (10 * n[l] + 9 * n[l + 1]) for l in range(L - 1)) + 4 * 10 * n[L - 1]
-    line = sum(2 * 7 * 4 * n[l] for l in range(L - 1))  # one recursive pass: read 7 planes, write 7 planes
-    F = min(fused_sweep_levels, L - 1)  # levels whose anticausal-x and causal-y sweeps are one kernel (one R + one W)
-    fused = sum(2 * 7 * 4 * n[l] for l in range(F))
+    F = min(fused_sweep_levels, L - 1)
+    m0 = 6 if implicit_mask else 7  # level-0 planes that exist as inputs of the blur
+    x_fwd = x_bwd = y_fwd = y_bwd = xbyf = 0
+    for l in range(L - 1):
+        rd = 4 * n[l] * (m0 if l == 0 else 7)
+        wr = 4 * n[l] * 7
+        if l == 0 and source_fused:
+            x_fwd += inputs + 4 * P + 4 * n[0] * m0  # frames + index plane in, six (or seven) x-swept planes out
+        else:
+            x_fwd += rd + (4 * n[l] * m0 if l == 0 else wr)
+        if l < F:
+            xbyf += rd + wr
+        else:
+            x_bwd += rd + (4 * n[l] * m0 if l == 0 else wr)
+            y_fwd += wr + wr
+        y_bwd += wr + (7 * 4 * n[l + 1] if fused_decimate else wr)
+    decimate = 0 if fused_decimate else sum(7 * 4 * (n[l] + n[l + 1]) for l in range(L - 1))
+    if L > 1:
+        g0_in = (inputs + 4 * P) if source_fused else 4 * 6 * P
+        collapse_l0 = g0_in + (0 if implicit_mask else 4 * P) + 4 * 9 * n[1] + 3 * P * bytes_per_sample
+    else:
+        collapse_l0 = 0
     per_kernel = {
-        "compose": s1,
-        "seam": 2 * 4 * level_w[0],  # two mid rows
-        "mask": 4 * P,               # the step written once (when it is materialised at all)
-        "vv_x_fwd": line, "vv_x_bwd": line - fused, "vv_y_fwd": line - fused, "vv_y_bwd": line, "vv_xbyf": fused,
-        "decimate": sum(7 * 4 * (n[l] + n[l + 1]) for l in range(L - 1)),
+        "compose": 4 * P if source_fused else s1,  # source-fused: the index plane
+        "seam": 2 * bytes_per_sample * level_w[0],  # two mid rows
+        "mask": 0 if implicit_mask else 4 * P,
+        "vv_x_fwd": x_fwd, "vv_x_bwd": x_bwd, "vv_y_fwd": y_fwd, "vv_y_bwd": y_bwd, "vv_xbyf": xbyf,
+        "decimate": decimate,
         "collapse_top": 4 * 10 * n[L - 1],
         "collapse": sum(4 * (10 * n[l] + 9 * n[l + 1]) for l in range(1, L - 1)),
-        "collapse_l0": 4 * (10 * n[0] + 9 * n[1]) if L > 1 else 0,
+        "collapse_l0": collapse_l0,
     }
     return per_kernel, {"S1": s1, "S2": s2, "S3": s3, "total": s1 + s2 + s3}
 
 
-class PairStitcher:
-    """warp + move + blend of independent pairs on one GPU with a workspace allocated once (stitch_plan)."""
-
-    def __init__(self, cw, ch, opts=None):
-        self.plan = capi.Plan(cw, ch, opts)
-        self.cw, self.ch = cw, ch
-
-    def run(self, frame, p, mosaic, out=None, offx=0.0, offy=0.0, ox=0, oy=0):
-        return self.plan.pair(frame, p, offx, offy, mosaic, ox, oy, out)
-
-    def close(self):
-        self.plan.close()
+def batches_of(n_pairs, rank, world, batch):
+    """Config 4 as a schedule: this rank's contiguous shard of an n_pairs batch, cut into launch sequences of at most
+    `batch` pairs -> list of (first, last+1) global pair indices."""
+    lo, hi = shard_range(n_pairs, rank, world)
+    return [(b, min(b + batch, hi)) for b in range(lo, hi, batch)]
 
 
 def stitch_chain(frames, steps, opts=None, finish=True, num=19.0, den=20.0, plans=None):
@@ -125,8 +146,8 @@ def levels_of(cw, ch, level_rule=0):
 
 
 class MosaicGather:
-    """Assembles a sharded batch on every rank: each rank contributes one finished uint8 mosaic per step and the
-    step's mosaics of all ranks are all-gathered (torch.distributed: backend "nccl" = RCCL over xGMI on the GPUs;
+    """Assembles a sharded batch on every rank: each rank contributes one block per step (`shape`: one finished uint8
+    mosaic, or its whole shard of the step's batch, (n, 3, H, W)) and the step's blocks of all ranks are all-gathered (torch.distributed: backend "nccl" = RCCL over xGMI on the GPUs;
     "gloo" on CPU tensors in the tests).  The collective is asynchronous, so on the GPU it overlaps the next pair's
     kernels; a ring of `slots` input/output buffers bounds memory.  With keep=True every step's gathered block is
     retained (tests / small batches): result()[k, r] is the mosaic rank r produced at step k.
@@ -144,11 +165,12 @@ class MosaicGather:
         self.works = [None] * slots
 
     def input_slot(self, k):
-        """Buffer to fill with step k's local mosaic; first waits for the gather that last used the slot."""
+        """Buffer to fill with step k's local mosaic(s); first waits for the gather that last used the slot.  May be
+        called from several streams for the same step (each launch sequence of a step fills its own part of the block):
+        every caller's stream waits, the handle is only replaced by submit()."""
         s = k % self.slots
         if self.works[s] is not None:
             self.works[s].wait()
-            self.works[s] = None
         return self.inp[s]
 
     def submit(self, k):

@@ -147,6 +147,8 @@ int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
  *   STITCH_CROWS_L0=<n>       rows per work-item strip of the level-0 collapse (default 32)
  *   STITCH_CROWS_LN=<n>       the same for the levels above (default 32)
  *   STITCH_XBYF_WGS=<n>       persistent workgroups of the fused sweep (default 2304)
+ *   STITCH_XBYF_SPIN_LIMIT=<n> polls before a hand-off wait of the fused sweep gives up (default 2^20; 0 forces the
+ *                             bail-out path: tests of the sticky time-out report)
  *   STITCH_XBYF_EARLY=0       fused sweep: poll for the hand-off only when it is needed (default: read it ahead of the prefetch)
  * The stitch_dev_pairs_* launch sequence contains no host synchronisation and no per-launch state in kernel
  * arguments: it may be captured into a HIP graph and replayed on new contents of the same buffers. */
@@ -172,10 +174,19 @@ typedef struct stitch_pair_desc {
 } stitch_pair_desc;
 int stitch_dev_pairs_u8(stitch_plan *plan, const stitch_pair_desc *pairs, int n, void *stream);
 int stitch_dev_pairs_f32(stitch_plan *plan, const stitch_pair_desc *pairs, int n, void *stream);
-/* Waits for the plan's last call to finish and reports its seam outcome: STITCH_OK, STITCH_ERR_EMPTY_MIDROW or
- * STITCH_ERR_ZERO_OVERLAP (in the error cases the output buffer holds unspecified finite values). */
+/* Waits for the plan's last call to finish and reports its outcome: STITCH_OK, STITCH_ERR_EMPTY_MIDROW or
+ * STITCH_ERR_ZERO_OVERLAP for the seam scan of pair `index` of the LAST call (in these cases the output buffer holds
+ * unspecified finite values), or STITCH_ERR_HIP when a hand-off wait of the fused sweep (k_vv_xbyf) timed out.  The
+ * time-out is STICKY: the plan counts timed-out waits in a device word that no launch sequence clears, so a bail-out in
+ * ANY call queued on the plan since the last stitch_plan_clear_fault is reported here (the outputs of every call since
+ * then are invalid), not just one in the last call. */
 int stitch_plan_status(stitch_plan *plan, stitch_seam *seam_out);                   /* pair 0 */
 int stitch_plan_status_at(stitch_plan *plan, int index, stitch_seam *seam_out);    /* pair `index` of a batch */
+/* Acknowledges the time-outs reported so far (after the caller has discarded the affected outputs). */
+int stitch_plan_clear_fault(stitch_plan *plan);
+/* Polls before a hand-off wait of the fused sweep gives up, for the calls enqueued from now on (default 2^20, about a
+ * second; 0 = give up at the first check, which is how the tests reach the time-out report). */
+int stitch_plan_set_handoff_spin_limit(stitch_plan *plan, unsigned polls);
 
 /* Per-kernel device timing of a plan's calls, with HIP events recorded on the call's stream around every
  * launch.  Kernel ids: */

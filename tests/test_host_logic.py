@@ -18,15 +18,35 @@ def test_shard_range_covers_everything_once():
 
 def test_algorithmic_bytes_match_survey():
     """config-2 canvas 6144x4096 (L=12) -> 1.007 + 3.053 + 1.644 = 5.704 GB per pair."""
-    lw = [6144 >> i for i in range(12)]
+    lw = lw0 = [6144 >> i for i in range(12)]
     lh = [4096 >> i for i in range(12)]
-    per_kernel, st = pipeline.algorithmic_bytes(4096 * 4096, 4096 * 4096, lw, lh, 4)
+    per_kernel, st = pipeline.algorithmic_bytes(4096 * 4096, 4096 * 4096, lw, lh, 4, fused_decimate=False)
     assert round(st["S1"] / 1e9, 3) == 1.007 and round(st["S2"] / 1e9, 3) == 3.053 and round(st["S3"] / 1e9, 3) == 1.644
     assert round(st["total"] / 1e9, 3) == 5.704
     lw = [4096 >> i for i in range(12)]
     _, st2 = pipeline.algorithmic_bytes(4096 * 4096, 4096 * 4096, lw, lw, 4)
     assert round(st2["total"] / 1e9, 3) == 3.937  # the 4096x4096 canvas figure of the same section
     assert per_kernel["collapse"] + per_kernel["collapse_l0"] + per_kernel["collapse_top"] == st["S3"] and per_kernel["compose"] == st["S1"]
+    # with the fusion the benchmarked plan runs, every kernel is credited only what it moves itself: the fused anticausal-y
+    # + decimation reads level l and writes level l+1; the fused sweep reads 6 and writes 7 planes at level 0 (the mask is
+    # implicit); source-fused, S1 is one 4-byte index plane and level 0 is gathered from the frames
+    pk, st3 = pipeline.algorithmic_bytes(4096 * 4096, 4096 * 4096, lw0, lh, 4, 2, True, True, True)
+    n = [w * h for w, h in zip(lw0, lh)]
+    assert st3 == st
+    assert pk["vv_y_bwd"] == sum(7 * 4 * (n[l] + n[l + 1]) for l in range(11)) and pk["decimate"] == 0
+    assert pk["vv_xbyf"] == 4 * n[0] * (6 + 7) + 4 * n[1] * 14
+    assert pk["compose"] == 4 * n[0] and pk["mask"] == 0
+    inputs = 2 * 4096 * 4096 * 3 * 4
+    assert pk["collapse_l0"] == inputs + 4 * n[0] + 4 * 9 * n[1] + 3 * 4 * n[0]
+    assert sum(pk.values()) < 1.1 * st["total"]  # the fused design moves about what the canonical accounting counts
+
+
+def test_batches_of_is_the_config4_schedule():
+    assert pipeline.batches_of(32, 3, 8, 8) == [(12, 16)]  # 8 GPUs: one launch sequence of 4 pairs per rank and step
+    assert pipeline.batches_of(32, 0, 1, 8) == [(0, 8), (8, 16), (16, 24), (24, 32)]
+    assert pipeline.batches_of(32, 1, 2, 8) == [(16, 24), (24, 32)]
+    assert pipeline.batches_of(5, 0, 2, 2) == [(0, 2), (2, 3)] and pipeline.batches_of(5, 1, 2, 2) == [(3, 5)]
+    assert pipeline.batches_of(3, 3, 4, 8) == []
 
 
 def test_config_recipes():

@@ -75,6 +75,71 @@ def test_sharded_batch_world2(tmp_path, oracle):
     assert seen == set(range(N_PAIRS))
 
 
+def _block_worker(rank, world, port, outdir):
+    """bench.py's exchange at N>1: per step every rank fills ITS block of the step's batch (n_max mosaics, filled by
+    several launch sequences) and the blocks are all-gathered; two buffer slots are cycled over three steps."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from computervisionimagestich2_amd import pipeline
+    from oracle_lib import Oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O = Oracle()
+    O.set_threads(1)
+    P, STEPS, B = 6, 3, 1  # 6 pairs on 4 ranks: shards of 2, 2, 1, 1 -> ragged blocks; one pair per launch sequence
+    lo, hi = pipeline.shard_range(P, rank, world)
+    n_max = pipeline.shard_range(P, 0, world)[1]
+    seqs = pipeline.batches_of(P, rank, world, B)
+    g = pipeline.MosaicGather((n_max, 3, CH, CW), torch.device("cpu"), world, rank, slots=2, keep=True, steps=STEPS, force_collective=True)
+    for k in range(STEPS):
+        for (a, b) in seqs:  # every launch sequence asks for the step's block itself, as bench.py's lanes do
+            blk = g.input_slot(k)
+            for i in range(a, b):
+                blk[i - lo].copy_(torch.from_numpy(_pair(O, i)) + k)  # + k: a stale slot would be noticed
+        for j in range(hi - lo, n_max):
+            g.input_slot(k)[j].zero_()
+        g.submit(k)
+    g.drain()
+    np.save(os.path.join(outdir, f"rank{rank}.npy"), g.result().numpy())
+    # the verification collective of bench.py: per-pair checksums of every rank
+    mine = torch.tensor([int(g.result()[STEPS - 1, rank, j].to(torch.int64).sum()) for j in range(n_max)], dtype=torch.int64)
+    allq = torch.empty(world * n_max, dtype=torch.int64)
+    dist.all_gather_into_tensor(allq, mine)
+    for r in range(world):
+        for j in range(n_max):
+            assert int(g.result()[STEPS - 1, r, j].to(torch.int64).sum()) == int(allq[r * n_max + j])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_block_gather_world4_ragged(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    from computervisionimagestich2_amd import pipeline
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_block_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    res = [np.load(tmp_path / f"rank{r}.npy") for r in range(4)]
+    for r in range(1, 4):
+        assert np.array_equal(res[0], res[r]), "every rank must hold the same assembled batch"
+    P = 6
+    for k in range(3):
+        seen = []
+        for r in range(4):
+            lo, hi = pipeline.shard_range(P, r, 4)
+            for j in range(2):
+                if lo + j < hi:
+                    assert np.array_equal(res[0][k, r, j], _pair(oracle, lo + j) + k), (k, r, j)
+                    seen.append(lo + j)
+                else:
+                    assert not res[0][k, r, j].any()
+        assert seen == list(range(P))
+
+
 def test_gather_world1_is_identity():
     import torch
     from computervisionimagestich2_amd import pipeline
