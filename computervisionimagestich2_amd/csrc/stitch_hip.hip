@@ -164,6 +164,7 @@ struct Level {
     float* e;        // 3 planes (collapse chain), levels >= 1
     int32_t *ix, *iy;  // expand tables level+1 -> level (levels < L-1)
     double *ax, *ay;
+    int c4_xa, c4_xb;  // columns [c4_xa, c4_xb) of this level go to k_collapse4 (multiples of 256; empty when equal)
 };
 
 constexpr int WF_CTRL_WORDS = 4 * 16 + 16;  // band-queue heads of up to 4 levels (64 bytes apart) + the abort word
@@ -206,8 +207,12 @@ struct stitch_plan {
     unsigned wf_abort_seen = 0;  // count already acknowledged by stitch_plan_clear_fault
     float* side = nullptr;  // [cap][pitch0] x-blurred level-0 mask rows (implicit level-0 mask)
     bool mask_opt = false;  // level-0 mask handled implicitly (Van Vliet, level-0 height a multiple of 64)
-    int crows_ln = 4 * CROWS;  // rows per strip of the collapse at levels >= 1 (STITCH_CROWS_LN): slower alone than 8, fewer bytes with other batches in flight
-    int crows_l0 = 4 * CROWS;  // rows per work-item strip of the level-0 collapse (fewer re-reads of level-1 rows)
+    // rows per work-item strip of the collapse (a strip re-uses its x-interpolated source rows from output row to output
+    // row, and its rows are one serial chain of load latencies): 32 at the large levels (fewer re-reads of level l+1), h/32
+    // but at least 4 at the small ones, whose launches are nothing but that chain.  STITCH_CROWS_L0 / STITCH_CROWS_LN override.
+    int crows_ln = 0;  // 0 = per level, crows_of()
+    int crows_l0 = 4 * CROWS;
+    bool collapse4 = true;  // four columns per work-item in the collapse where possible (STITCH_COLLAPSE4=0: always k_collapse)
     bool src_fuse = false;  // pairs: level-0 planes evaluated from the frames by their consumers, k_compose never runs
     SeamDev* d_seam = nullptr;
     SeamDev* h_seam = nullptr;  // pinned
@@ -383,6 +388,12 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
     return launch_check("reduce");
 }
 
+int crows_of(const stitch_plan* p, int l) {
+    if (l == 0) return p->crows_l0;
+    if (p->crows_ln > 0) return p->crows_ln;
+    return std::max(4, std::min(4 * CROWS, p->lv[l].h / 32));
+}
+
 template <typename OUT>
 int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s, const PairArgs<OUT>& pa, bool src) {
     const int L = p->L;
@@ -396,17 +407,35 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
         const Level& a = p->lv[l];
         const Level& nx = p->lv[l + 1];
         StageTimer tm(p, s, l == 0 ? STITCH_K_COLLAPSE_L0 : STITCH_K_COLLAPSE, l);
-        ExpandTab tb{a.ix, a.ax, a.iy, a.ay};
-        if (l == 0)  // level 0: the mask is the seam's step function itself (never read from memory)
-            k_collapse<OUT, true><<<grid_xy(a.w, (a.h + p->crows_l0 - 1) / p->crows_l0, n), 256, 0, s>>>(
-                a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, tb, outs, a.w, (size_t)a.w * a.h, p->d_seam, pa,
-                src ? 1 : 0, p->crows_l0);
-        else {
+        // four columns per work-item on the column range whose taps follow the regular pattern (Level::c4_xa, c4_xb), one
+        // column per work-item on the rest, in ONE launch (k_collapse4); levels without such a range run k_collapse
+        int xa = 0, xb = 0;
+        if (p->collapse4) xa = a.c4_xa, xb = a.c4_xb;
+        if (l == 0) {
+            bool ok = (a.w % 4) == 0;
+            for (int i = 0; i < n; ++i) ok = ok && (reinterpret_cast<uintptr_t>(outs.p[i]) % (4 * sizeof(OUT))) == 0;
+            if (!ok) xa = xb = 0;
+        }
+        const int cols = l == 0 ? a.w : a.pitch, rest = cols - (xb - xa);
+        const int nb4 = ((xb - xa) / 4 + WAVE - 1) / WAVE, ncb = (rest + C4_THREADS - 1) / C4_THREADS;
+        if (l == 0) {  // level 0: the mask is the seam's step function itself (never read from memory)
+            CollapseArgs<OUT, true> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, outs,
+                                      a.w, (size_t)a.w * a.h, p->d_seam, pa, src ? 1 : 0, p->crows_l0, xa, xb};
+            const int strips = (a.h + p->crows_l0 - 1) / p->crows_l0;
+            if (xb > xa)
+                k_collapse4<OUT, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
+            else
+                k_collapse<OUT, true><<<grid_xy(cols, strips, n), 256, 0, s>>>(A);
+        } else {
             OutPtrs<float> eo{};
             eo.p[0] = a.e;
-            k_collapse<float, false><<<grid_xy(a.pitch, (a.h + p->crows_ln - 1) / p->crows_ln, n), 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w,
-                                                                              nx.h, nx.pitch, nx.ps, tb, eo, a.pitch, a.ps, nullptr,
-                                                                              NoPairArgs{}, 0, p->crows_ln);
+            CollapseArgs<float, false> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, eo,
+                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb};
+            const int strips = (a.h + A.crows - 1) / A.crows;
+            if (xb > xa)
+                k_collapse4<float, false><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
+            else
+                k_collapse<float, false><<<grid_xy(cols, strips, n), 256, 0, s>>>(A);
         }
     }
     return launch_check("collapse");
@@ -978,6 +1007,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     {
         if (const char* c = getenv("STITCH_CROWS_L0")) p->crows_l0 = std::max(1, atoi(c));
         if (const char* c = getenv("STITCH_CROWS_LN")) p->crows_ln = std::max(1, atoi(c));
+        if (const char* c = getenv("STITCH_COLLAPSE4")) p->collapse4 = atoi(c) != 0;
         const char* e = getenv("STITCH_NO_SRC_FUSE");  // A/B and tests: keep S1 as its own kernel (k_compose)
         p->src_fuse = p->mask_opt && !(e && atoi(e) != 0);
     }
@@ -992,6 +1022,25 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         std::vector<int32_t> idx;
         std::vector<double> al;
         expand_table(lw[l + 1], v.w, idx, al);
+        {   // the longest run of 256-column blocks in which every group of four columns x0.. has the taps s, s+1, s+1, s+2
+            // with s+3 inside the source row (see k_collapse4); short levels are left to k_collapse
+            v.c4_xa = v.c4_xb = 0;
+            int best_a = 0, best_b = 0, run_a = -1;
+            const int nblk = v.w / 256;
+            for (int b = 0; b <= nblk; ++b) {
+                bool reg = b < nblk && lw[l + 1] >= 2 && lh[l + 1] >= 2;
+                for (int x0 = b * 256; reg && x0 < (b + 1) * 256; x0 += 4) {
+                    const int s_ = idx[x0];
+                    reg = idx[x0 + 1] == s_ + 1 && idx[x0 + 2] == s_ + 1 && idx[x0 + 3] == s_ + 2 && s_ + 3 <= lw[l + 1] - 1;
+                }
+                if (reg && run_a < 0) run_a = b;
+                if (!reg && run_a >= 0) {
+                    if (b - run_a > best_b - best_a) best_a = run_a, best_b = b;
+                    run_a = -1;
+                }
+            }
+            if (best_b > best_a) v.c4_xa = best_a * 256, v.c4_xb = best_b * 256;
+        }
         (void)hipMemcpy(v.ix, idx.data(), sizeof(int32_t) * v.w, hipMemcpyHostToDevice);
         (void)hipMemcpy(v.ax, al.data(), sizeof(double) * v.w, hipMemcpyHostToDevice);
         expand_table(lh[l + 1], v.h, idx, al);

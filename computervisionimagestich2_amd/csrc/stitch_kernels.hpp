@@ -1908,19 +1908,36 @@ __device__ __forceinline__ void level_ab(const NoPairArgs&, int, int, const floa
         b[c] = g[o + (3 + c) * ps];
     }
 }
+// everything a collapse launch of one level needs (kernel argument)
 template <typename OUT, bool DENSE>
-__global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_all, int w, int h, int pitch, size_t ps,
-                                                  const float* __restrict__ gn_all, const float* __restrict__ en_all, int sw,
-                                                  int sh, int spitch, size_t sps, ExpandTab tb, OutPtrs<OUT> outs,
-                                                  int opitch, size_t ops, const SeamDev* __restrict__ seam_l0,
-                                                  typename CollapseSrc<OUT, DENSE>::type pa, int use_src, int crows) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * crows, pr = blockIdx.z;
-    if (x >= (DENSE ? w : pitch)) return;
-    const float* g = g_all + (size_t)pr * 7 * ps;
-    const float* gn = gn_all + (size_t)pr * 7 * sps;
-    const float* en = en_all + (size_t)pr * 3 * sps;
-    OUT* __restrict__ out = DENSE ? outs.p[pr] : outs.p[0] + (size_t)pr * 3 * ops;
-    const int y1 = min(y0 + crows, h);
+struct CollapseArgs {
+    const float* g_all;  // level l: 7 planes per pair (plane 0 = the index plane when source-fused)
+    int w, h, pitch;
+    size_t ps;
+    const float *gn_all, *en_all;  // level l+1: G (7 planes per pair) and E (3 planes per pair)
+    int sw, sh, spitch;
+    size_t sps;
+    ExpandTab tb;
+    OutPtrs<OUT> outs;
+    int opitch;
+    size_t ops;
+    const SeamDev* seam_l0;  // level 0: the mask is the seam's step function
+    typename CollapseSrc<OUT, DENSE>::type pa;
+    int use_src, crows;
+    int xa, xb;  // columns [xa, xb) are done four per work-item (collapse_cols4), the rest one per work-item
+};
+
+// one column x, rows [y0, y1) of pair pr
+template <typename OUT, bool DENSE>
+__device__ __forceinline__ void collapse_cols1(const CollapseArgs<OUT, DENSE>& A, int x, int y0, int y1, int pr) {
+    const int w = A.w, pitch = A.pitch, sw = A.sw, sh = A.sh, spitch = A.spitch, opitch = A.opitch;
+    const size_t ps = A.ps, sps = A.sps, ops = A.ops;
+    const ExpandTab& tb = A.tb;
+    const SeamDev* __restrict__ seam_l0 = A.seam_l0;
+    const float* g = A.g_all + (size_t)pr * 7 * ps;
+    const float* gn = A.gn_all + (size_t)pr * 7 * sps;
+    const float* en = A.en_all + (size_t)pr * 3 * sps;
+    OUT* __restrict__ out = DENSE ? A.outs.p[pr] : A.outs.p[0] + (size_t)pr * 3 * ops;
     if (!DENSE && x >= w) {
         for (int y = y0; y < y1; ++y)
 #pragma unroll
@@ -1964,7 +1981,7 @@ __global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_al
         const size_t o = (size_t)y * pitch + x;
         const float m = seam_l0 ? m_step : g[o + 6 * ps];
         float ga[3], gb[3];
-        level_ab(pa, pr, use_src, g, o, ps, x, y, ga, gb);
+        level_ab(A.pa, pr, A.use_src, g, o, ps, x, y, ga, gb);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float ea = y_nearest ? X1[c] : lerp_ref(ay, X1[c], X2[c]);
@@ -1983,6 +2000,271 @@ __global__ __launch_bounds__(256) void k_collapse(const float* __restrict__ g_al
             else
                 out[(size_t)y * opitch + x + c * ops] = px_store<OUT>(v);
         }
+    }
+}
+
+// one column per work-item over the whole level (xa == xb) -- levels too small or too irregular for k_collapse4
+template <typename OUT, bool DENSE>
+__global__ __launch_bounds__(256) void k_collapse(CollapseArgs<OUT, DENSE> A) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * A.crows, pr = blockIdx.z;
+    if (x >= (DENSE ? A.w : A.pitch)) return;
+    collapse_cols1<OUT, DENSE>(A, x, y0, min(y0 + A.crows, A.h), pr);
+}
+
+// ---- the same collapse, four columns and ONE channel per work-item ------------------------------------------------
+// k_collapse moves 4 bytes per lane and access and spends as many instructions on addresses and table look-ups as on
+// the arithmetic.  Here a work-item owns FOUR adjacent columns x0..x0+3 (x0 a multiple of 4) of a strip of rows of ONE
+// colour channel; the three wavefronts of a workgroup are the three channels of the same 256 columns.  The level's own
+// planes (G_l, the mask, the index plane of a source-fused level 0, the output) are moved 16 bytes per lane, table
+// entries are read once per strip, and -- the point of the channel split -- the x-interpolated source rows a work-item
+// keeps are 2 x 3 planes x 4 columns = 24 registers instead of 72, so that 7-8 wavefronts per SIMD are resident instead
+// of 2-3: the kernel is a chain of dependent loads per row (index -> gather -> arithmetic -> store) and lives on the
+// number of such chains in flight.  The channels of a tile share its index and mask loads through the CU's L1.
+// The up-sampling step is (sw-1)/(w-1) < 1/2, and away from the ends of a row the x taps follow one pattern:
+// ix[x0..x0+3] = s, s+1, s+1, s+2 (columns 2m, 2m+1 interpolate between samples m-1, m and m, m+1 while the accumulated
+// step stays within half a sample of x/2), so the taps of the four columns are fixed elements of ONE 4-byte-aligned
+// 16-byte load at s.  The host knows the tables and hands this path only the column range [xa, xb) where every group of
+// four has that pattern (6144 -> all but the first 256 columns); the other columns run collapse_cols1 in the same launch.
+// Arithmetic and its order per sample are k_collapse's (lerp_ref, blend_ref, clamp).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment (dword-aligned dwordx4)
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+template <typename OUT>
+__device__ __forceinline__ void store4(OUT* p, const float v[4]);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, const float v[4]) {
+    __builtin_nontemporal_store(f4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f4*>(p));
+}
+template <>
+__device__ __forceinline__ void store4<uint8_t>(uint8_t* p, const float v[4]) {
+    const unsigned w = (unsigned)(uint8_t)(int)v[0] | ((unsigned)(uint8_t)(int)v[1] << 8) | ((unsigned)(uint8_t)(int)v[2] << 16) |
+                       ((unsigned)(uint8_t)(int)v[3] << 24);
+    __builtin_nontemporal_store(w, reinterpret_cast<unsigned*>(p));
+}
+
+// level-0 samples of channel c at four adjacent canvas columns of a source-fused plan (what k_compose would have stored)
+template <typename PX>
+struct SrcRow4 {
+    __amdgpu_buffer_rsrc_t fr, mo;
+    int mw, mh, ox, oy;
+    bool m_all, m_col[4];  // x part of the mosaic range test for this lane's columns
+    unsigned m_x0;         // byte offset of column x0 within a mosaic row (valid when m_col[0])
+    __device__ __forceinline__ SrcRow4(const PairArgs<PX>& pa, int pr, int c, int x0, int w) {
+        const size_t fe = (size_t)pa.fw[pr] * pa.fh[pr], me = (size_t)pa.mw[pr] * pa.mh[pr];
+        fr = plane_rsrc(pa.frame[pr] + c * fe, fe);
+        mo = plane_rsrc(pa.mosaic[pr] + c * me, me);
+        mw = pa.mw[pr];
+        mh = pa.mh[pr];
+        ox = pa.ox[pr];
+        oy = pa.oy[pr];
+        m_all = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long mx = (long long)(x0 + j) + ox;
+            m_col[j] = x0 + j < w && mx >= 0 && mx < mw;
+            m_all = m_all && m_col[j];
+        }
+        m_x0 = (unsigned)((long long)x0 + ox) * (unsigned)sizeof(PX);
+    }
+    // raw bits of a[j], b[j] of canvas row y (loads only: nothing here waits for them); idx = the four byte offsets
+    // k_src_index left (or "outside")
+    __device__ __forceinline__ void issue(const u4 idx, int y, float a[4], float b[4]) const {
+        const long long my = (long long)y + oy;
+        const bool row_ok = my >= 0 && my < mh;  // wave-uniform
+        const unsigned rowb = (unsigned)my * (unsigned)mw * (unsigned)sizeof(PX);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = buf_raw<PX>(fr, idx[j]);  // "outside" is beyond the plane: reads 0
+        if (row_ok) {
+            if (sizeof(PX) == 4 && __all(m_all)) {  // the common case: four consecutive floats, dword-aligned
+                const u4 v = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(mo, rowb + m_x0, 0, 0));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = __uint_as_float(v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = buf_raw<PX>(mo, m_col[j] ? rowb + m_x0 + (unsigned)(j * sizeof(PX)) : off_outside<PX>());
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = 0.f;  // raw 0 = sample 0 in either pixel type
+        }
+    }
+    // raw bits -> the values k_compose would have stored
+    __device__ __forceinline__ void finish(float a[4], float b[4]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = (float)px_store<PX>(warp_tap(raw_to_px<PX>(a[j])));
+            b[j] = raw_to_px<PX>(b[j]);
+        }
+    }
+};
+struct NoSrcRow4 {
+    __device__ __forceinline__ NoSrcRow4(const NoPairArgs&, int, int, int, int) {}
+    __device__ __forceinline__ void issue(const u4, int, float[4], float[4]) const {}
+    __device__ __forceinline__ void finish(float[4], float[4]) const {}
+};
+template <typename OUT, bool DENSE>
+struct SrcRow4Of {
+    typedef NoSrcRow4 type;
+};
+template <typename OUT>
+struct SrcRow4Of<OUT, true> {
+    typedef SrcRow4<OUT> type;
+};
+
+#ifndef STITCH_C4_WAVES
+#define STITCH_C4_WAVES 7  // <= 72 registers: 7 wavefronts per SIMD (measured, level 0 of 8 config-2 pairs: 4 -> 2.39 ms, 6 -> 1.75, 7 -> 1.67, 8 with spills -> 1.70)
+#endif
+#ifndef STITCH_C4_PREFETCH
+#define STITCH_C4_PREFETCH 0
+#endif
+#ifndef STITCH_C4_OPAQUE_ALPHA
+#define STITCH_C4_OPAQUE_ALPHA 1
+#endif
+// channel c of columns x0..x0+3, rows [y0, y1) of pair pr
+template <typename OUT, bool DENSE>
+__device__ __forceinline__ void collapse_cols4(const CollapseArgs<OUT, DENSE>& A, int c, int x0, int y0, int y1, int pr) {
+    const int pitch = A.pitch, sh = A.sh, spitch = A.spitch, opitch = A.opitch;
+    const size_t ps = A.ps, sps = A.sps, ops = A.ops;
+    const ExpandTab& tb = A.tb;
+    const SeamDev* __restrict__ seam_l0 = A.seam_l0;
+    const float* g = A.g_all + (size_t)pr * 7 * ps;
+    // the three planes of level l+1 this channel expands: a_c, b_c of G_{l+1} and channel c of E_{l+1}
+    const float* sa = A.gn_all + ((size_t)pr * 7 + c) * sps;
+    const float* sb = sa + 3 * sps;
+    const float* se = A.en_all + ((size_t)pr * 3 + c) * sps;
+    OUT* __restrict__ out = (DENSE ? A.outs.p[pr] : A.outs.p[0] + (size_t)pr * 3 * ops) + c * ops;
+    const bool use_src = DENSE && A.use_src;
+    // table entries of the four columns; their taps are samples s0 .. s0+3 of a source row
+    const int s0 = tb.ix[x0];
+    double axs[4];
+    {
+        const double2 a01 = *reinterpret_cast<const double2*>(tb.ax + x0), a23 = *reinterpret_cast<const double2*>(tb.ax + x0 + 2);
+        axs[0] = a01.x, axs[1] = a01.y, axs[2] = a23.x, axs[3] = a23.y;
+    }
+    // x pass of one source row for the three planes
+    auto xrow = [&](int row, float X[3][4]) {
+        const unsigned o = (unsigned)row * (unsigned)spitch + (unsigned)s0;
+        const f4 v[3] = {*reinterpret_cast<const f4u*>(sa + o), *reinterpret_cast<const f4u*>(sb + o), *reinterpret_cast<const f4u*>(se + o)};
+#if STITCH_C4_OPAQUE_ALPHA
+        // registers are what bounds the number of resident wavefronts here: keep the four alphas, not also the four
+        // (1 - alpha) the compiler would hoist out of the row loop (recomputed per source row: four v_add_f64)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(axs[j]));
+#endif
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            X[q][0] = lerp_ref(axs[0], v[q].x, v[q].y);
+            X[q][1] = lerp_ref(axs[1], v[q].y, v[q].z);
+            X[q][2] = lerp_ref(axs[2], v[q].y, v[q].z);
+            X[q][3] = lerp_ref(axs[3], v[q].z, v[q].w);
+        }
+    };
+    float X1[3][4], X2[3][4];
+    int cur1 = -1, cur2 = -1;
+    float m4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (seam_l0) {  // level 0: the mask is the step itself
+        const SeamDev sd = seam_l0[pr];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m4[j] = mask_step(sd, x0 + j);
+    }
+    const typename SrcRow4Of<OUT, DENSE>::type src(A.pa, pr, c, x0, A.w);
+    // the level's own samples of one row, as raw bits: two planes (or the gathers of a source-fused level 0) + the mask
+    auto row_issue = [&](int y, float ga[4], float gb[4], f4& vm) {
+        const unsigned o = (unsigned)y * (unsigned)pitch + (unsigned)x0;
+        if (use_src)
+            src.issue(*reinterpret_cast<const u4*>(g + o), y, ga, gb);
+        else {
+            const f4 va = *reinterpret_cast<const f4*>(g + o + c * ps), vb = *reinterpret_cast<const f4*>(g + o + (3 + c) * ps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ga[j] = va[j], gb[j] = vb[j];
+        }
+        if (!seam_l0) vm = *reinterpret_cast<const f4*>(g + o + 6 * ps);
+    };
+    float ga[4], gb[4];
+    f4 vm = {0.f, 0.f, 0.f, 0.f};
+#if STITCH_C4_PREFETCH
+    // the row's loads are issued one row ahead of their use
+    float gan[4], gbn[4];
+    f4 vmn = {0.f, 0.f, 0.f, 0.f};
+    row_issue(y0, gan, gbn, vmn);
+#endif
+    for (int y = y0; y < y1; ++y) {
+        const int iy = tb.iy[y], iy2 = iy < sh - 1 ? iy + 1 : iy;
+        const double ay = tb.ay[y];
+        if (iy != cur1) {
+            if (iy == cur2) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) X1[q][j] = X2[q][j];
+            } else
+                xrow(iy, X1);
+            cur1 = iy;
+        }
+        if (iy2 != cur2) {
+            if (iy2 == cur1) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) X2[q][j] = X1[q][j];
+            } else
+                xrow(iy2, X2);
+            cur2 = iy2;
+        }
+#if STITCH_C4_PREFETCH
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ga[j] = gan[j], gb[j] = gbn[j];
+        vm = vmn;
+        if (y + 1 < y1) row_issue(y + 1, gan, gbn, vmn);  // behind the x pass: its loads are waited for at once
+#else
+        row_issue(y, ga, gb, vm);
+#endif
+        if (use_src) src.finish(ga, gb);
+        if (!seam_l0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m4[j] = vm[j];
+        }
+        float v4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ea = lerp_ref(ay, X1[0][j], X2[0][j]);
+            const float eb = lerp_ref(ay, X1[1][j], X2[1][j]);
+            const float ee = lerp_ref(ay, X1[2][j], X2[2][j]);
+            const float la = ga[j] - ea;
+            const float lb = gb[j] - eb;
+            const float s_ = blend_ref(la, lb, m4[j]);
+            float v = s_ + ee;
+            if (v > 255.f)
+                v = 255.f;
+            else if (v < 0.f)
+                v = 0.f;
+            v4[j] = v;
+        }
+        if constexpr (DENSE)
+            store4<OUT>(&out[(size_t)y * opitch + x0], v4);
+        else
+            *reinterpret_cast<f4*>(&out[(size_t)y * opitch + x0]) = f4{v4[0], v4[1], v4[2], v4[3]};
+    }
+}
+
+// One launch per level, workgroups of three wavefronts: workgroups [0, nb4) of a strip row do columns [xa, xb), four
+// columns per work-item, one channel per wavefront; the remaining workgroups do the other columns one per work-item
+// (all channels), each over an eighth of the strip's rows (that part is small, and a work-item's rows are a serial
+// chain of load latencies: short chains keep it off the launch's critical path).
+constexpr int C4_SUB = 8, C4_THREADS = 3 * WAVE;
+template <typename OUT, bool DENSE>
+__global__ __launch_bounds__(C4_THREADS, STITCH_C4_WAVES) void k_collapse4(CollapseArgs<OUT, DENSE> A, int nb4, int ncb) {
+    const int y0 = blockIdx.y * A.crows, pr = blockIdx.z, y1 = min(y0 + A.crows, A.h);
+    if ((int)blockIdx.x < nb4) {
+        const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // the channel is wave-uniform: plane bases stay scalar
+        const int x0 = A.xa + (blockIdx.x * WAVE + (threadIdx.x & 63)) * 4;
+        if (x0 < A.xb) collapse_cols4<OUT, DENSE>(A, c, x0, y0, y1, pr);
+    } else {
+        const int r = blockIdx.x - nb4, cb = r % ncb, sub = r / ncb, rows = (A.crows + C4_SUB - 1) / C4_SUB;
+        int x = cb * C4_THREADS + threadIdx.x;
+        if (x >= A.xa) x += A.xb - A.xa;
+        const int ya = y0 + sub * rows, yb = min(ya + rows, y1);
+        if (x < (DENSE ? A.w : A.pitch) && ya < yb) collapse_cols1<OUT, DENSE>(A, x, ya, yb, pr);
     }
 }
 

@@ -145,7 +145,9 @@ int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
  *   STITCH_NO_SRC_FUSE=1      materialise level 0 (k_compose) instead of gathering it from the frames where it is needed
  *   STITCH_NO_ZERO_TILES=1    store and re-read all-zero tiles of the blur scratch like any other tile
  *   STITCH_CROWS_L0=<n>       rows per work-item strip of the level-0 collapse (default 32)
- *   STITCH_CROWS_LN=<n>       the same for the levels above (default 32)
+ *   STITCH_CROWS_LN=<n>       the same for the levels above (default: per level, h/32 clamped to 4..32)
+ *   STITCH_COLLAPSE4=0        collapse with one column and three channels per work-item everywhere (k_collapse) instead of
+ *                             four columns of one channel where the resize taps are regular (k_collapse4)
  *   STITCH_XBYF_WGS=<n>       persistent workgroups of the fused sweep (default 2304)
  *   STITCH_XBYF_SPIN_LIMIT=<n> polls before a hand-off wait of the fused sweep gives up (default 2^20; 0 forces the
  *                             bail-out path: tests of the sticky time-out report)
