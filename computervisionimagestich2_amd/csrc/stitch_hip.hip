@@ -586,8 +586,43 @@ int dev_project(const PX* d_src, int w, int h, float fov_deg, PX* d_dst, void* s
     if (rc) return rc;
     if (!d_src || !d_dst || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "project: null buffer or bad size %dx%d", w, h);
     const ProjParams pp = proj_params(w, h, fov_deg);
-    k_project<PX><<<grid_xy(w, h), 256, 0, as_stream(stream)>>>(d_src, d_dst, w, h, pp.flag, pp.width, pp.height, pp.r, d_gray,
-                                                                d_gray_f32);
+    // portrait / square frames: source rows tiled into LDS (k_project_lds) when the largest source box of a tile fits the
+    // budget; everything else (landscape frames, widths that are not a multiple of 4, STITCH_PROJECT1=1): k_project
+    constexpr int TW = sizeof(PX) == 1 ? 256 : 64, TH = PJ_TH, CPX = PJ_CHUNK / (int)sizeof(PX);
+    size_t lds = 0;
+    bool tiled = !pp.flag && (w % 4) == 0 && (unsigned long long)w * h * 3 * sizeof(PX) < 0xfffffff0ULL &&
+                 (reinterpret_cast<uintptr_t>(d_src) % 4) == 0 && !std::getenv("STITCH_PROJECT1");
+    if (tiled) {
+        // the box of a tile, as the kernel derives it, over the tiles that can have the largest one (those farthest from the
+        // axis and from the middle row: the four corner tiles), plus a margin of two rows and two chunks
+        auto col_k = [&](int x) {
+            const float dst_x = (float)(x - w / 2);
+            const double rd = (double)pp.r, dx = (double)dst_x;
+            return (float)(rd / std::sqrt(rd * rd + dx * dx));
+        };
+        auto col_u = [&](int x) { return (float)(x - w / 2) / col_k(x) + (float)(w / 2); };
+        auto row_v = [&](int y, float k) { return (float)(y - h / 2) / k + (float)(h / 2); };
+        const int ntx = (w + TW - 1) / TW, nty = (h + TH - 1) / TH;
+        for (int by : {0, nty - 1})
+            for (int bx : {0, ntx - 1}) {
+                const int xa = bx * TW, ya = by * TH, xb = std::min(xa + TW, w) - 1, yb = std::min(ya + TH, h) - 1;
+                const int xmid = w / 2, xnear = xa <= xmid && xmid <= xb ? xmid : (std::abs(xa - xmid) < std::abs(xb - xmid) ? xa : xb),
+                          xfar = std::abs(xa - xmid) > std::abs(xb - xmid) ? xa : xb;
+                const float kn = col_k(xnear), kf = col_k(xfar);
+                const float vs[4] = {row_v(ya, kn), row_v(ya, kf), row_v(yb, kn), row_v(yb, kf)};
+                const float vmin = std::min(std::min(vs[0], vs[1]), std::min(vs[2], vs[3])), vmax = std::max(std::max(vs[0], vs[1]), std::max(vs[2], vs[3]));
+                const long rows = (long)std::ceil(vmax) - (long)std::floor(vmin) + 1 + 2;
+                const long cols = ((long)std::ceil(col_u(xb)) - (long)std::floor(col_u(xa)) + 1 + 2 * CPX + CPX - 1) / CPX * CPX;
+                lds = std::max(lds, (size_t)3 * rows * cols * sizeof(PX));
+            }
+        tiled = lds <= 60 * 1024;
+    }
+    if (tiled)
+        k_project_lds<PX, TW, TH><<<dim3((w + TW - 1) / TW, (h + TH - 1) / TH), 256, lds, as_stream(stream)>>>(d_src, d_dst, w, h, pp.r, d_gray,
+                                                                                                              d_gray_f32, (int)lds);
+    else
+        k_project<PX><<<grid_xy(w, h), 256, 0, as_stream(stream)>>>(d_src, d_dst, w, h, pp.flag, pp.width, pp.height, pp.r, d_gray,
+                                                                    d_gray_f32);
     return launch_check("k_project");
 }
 
@@ -717,6 +752,11 @@ int host_pair(const PX* frame, int fw, int fh, const double pm[8], float offx, f
     return STITCH_OK;
 }
 
+// planes of n bytes that can be moved as 32-bit words (the four-pixels-per-work-item kernels); STITCH_BYTE_KERNELS=1: never
+bool words_ok(const void* base, size_t n) {
+    return (n % 4) == 0 && (reinterpret_cast<uintptr_t>(base) % 4) == 0 && !std::getenv("STITCH_BYTE_KERNELS");
+}
+
 int eq_grid(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g < 2048 ? (g ? g : 1) : 2048);  // memory-bound: cap the grid and stride (guide 6, guideline 11)
@@ -735,12 +775,23 @@ int dev_equalize_impl(uint8_t* d_img, int w, int h, int32_t* d_hist_out, bool fu
     int32_t *hist = scratch, *lut = scratch + 256;
     HIPCHK(hipMemsetAsync(hist, 0, sizeof(int32_t) * 256, s));
     const size_t n = (size_t)w * h;
-    k_hist<<<eq_grid(n), HIST_WAVES * 64, 0, s>>>(d_img, n, hist);
-    k_lut<<<1, 64, 0, s>>>(hist, w, h, lut);
-    if (fuse_mix)
-        k_equalize_apply<true><<<eq_grid(n), 256, 0, s>>>(d_img, n, lut, num, den);
+    const bool v4 = words_ok(d_img, n);
+    if (v4)
+        k_hist4<<<eq_grid(n / 4), HIST_WAVES * 64, 0, s>>>(d_img, n, hist);
     else
-        k_equalize_apply<false><<<eq_grid(n), 256, 0, s>>>(d_img, n, lut, 0.0, 1.0);
+        k_hist<<<eq_grid(n), HIST_WAVES * 64, 0, s>>>(d_img, n, hist);
+    k_lut<<<1, 64, 0, s>>>(hist, w, h, lut);
+    if (fuse_mix) {
+        if (v4)
+            k_equalize_apply4<true><<<eq_grid(n / 4), 256, 0, s>>>(d_img, n, lut, num, den);
+        else
+            k_equalize_apply<true><<<eq_grid(n), 256, 0, s>>>(d_img, n, lut, num, den);
+    } else {
+        if (v4)
+            k_equalize_apply4<false><<<eq_grid(n / 4), 256, 0, s>>>(d_img, n, lut, 0.0, 1.0);
+        else
+            k_equalize_apply<false><<<eq_grid(n), 256, 0, s>>>(d_img, n, lut, 0.0, 1.0);
+    }
     if (d_hist_out) HIPCHK(hipMemcpyAsync(d_hist_out, hist, sizeof(int32_t) * 256, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipFreeAsync(scratch, s));
     return launch_check("equalize");

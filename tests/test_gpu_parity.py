@@ -36,7 +36,7 @@ def test_project_u8(st, gpu, oracle, w, h):
     assert np.array_equal(st.project(src), oracle.project(src))
 
 
-@pytest.mark.parametrize("w,h", [(384, 512), (640, 360), (33, 67)])
+@pytest.mark.parametrize("w,h", [(384, 512), (640, 360), (33, 67), (1000, 1000), (128, 300), (4, 4), (1028, 2050)])
 def test_project_f32(st, gpu, oracle, w, h):
     src = oracle.synth(w, h, 5, np.float32)
     got, ref = st.project(src), oracle.project(src)
@@ -153,7 +153,20 @@ def test_blend_errors(st, gpu, oracle):
     assert oracle.blend(A0, B)[0] == -2 and oracle.blend(A, B0)[0] == -3
 
 
-@pytest.mark.parametrize("w,h", [(1081, 527), (300, 200), (64, 64), (7, 5)])
+def test_project_column_strip_kernel_equals_pixel_kernel(st, gpu, oracle, monkeypatch):
+    """k_project4 (four columns per work-item, per-column constants hoisted) against k_project (STITCH_PROJECT1=1) and the
+    oracle, fused gray outputs included, on a frame whose rows are not a multiple of the strip height."""
+    src = oracle.synth(1236, 1019, 9, np.uint8)
+    a = st.capi.project_gray(src)
+    monkeypatch.setenv("STITCH_PROJECT1", "1")
+    b = st.capi.project_gray(src)
+    ref = oracle.project(src)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[0], ref)
+
+
+@pytest.mark.parametrize("w,h", [(1081, 527), (300, 200), (64, 64), (7, 5), (2048, 1024)])
 def test_equalize_lummix_finish(st, gpu, oracle, w, h):
     img = oracle.synth(w, h, 11, np.uint8)
     img[1] = np.maximum(img[1], 200)  # the 0.857 luma typo saturates bright pixels

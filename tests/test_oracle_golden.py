@@ -273,3 +273,18 @@ int main(void) {
                                os.path.join(d, "t.c"), "-lm"])
         n, bad_log, bad_pow, worst = subprocess.check_output([os.path.join(d, "t")]).split()
     assert int(n) > 100000 and int(bad_log) == 0 and int(bad_pow) == 0 and float(worst) < 4.5e-16
+
+
+def test_integer_luma_bin_is_exact(oracle):
+    """The histogram kernels bin a pixel with floor((299 R + 857 G + 114 B) / 1000), capped at 255, instead of the reference's
+    double -> float -> clamp -> truncate (equalization.cpp:78,83-85): checked here for ALL 2^24 colours, against the same
+    expression in numpy and against the oracle's own histogram of an image that holds every colour once."""
+    v = np.arange(256, dtype=np.float64)
+    R, G, B = np.meshgrid(v, v, v, indexing="ij")
+    Y = ((0.299 * R + 0.857 * G) + 0.114 * B).astype(np.float32)
+    Yc = np.where(Y > 0, np.where(Y < 256, Y, np.float32(255)), np.float32(0))
+    integ = np.minimum(255, ((299 * R + 857 * G + 114 * B).astype(np.int64)) // 1000)
+    assert np.array_equal(Yc.astype(np.int64), integ)
+    img = np.stack([R, G, B]).astype(np.uint8).reshape(3, 4096, 4096)
+    _, hist, _ = oracle.equalize(img)
+    assert np.array_equal(hist, np.bincount(integ.ravel(), minlength=256))
