@@ -25,6 +25,7 @@
 // equalization.o; for the three ImageProcess members (same translation unit as the control flow) either the
 // build-time excision of their bodies or symbol interposition (ImageProcess.cpp compiled -fPIC, this object ahead
 // of it in the lookup order) -- the latter is what tests/test_gpu_dropin.py exercises.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -39,6 +40,13 @@
 
 namespace {
 int g_calls[7] = {0, 0, 0, 0, 0, 0, 0};  // project, warp, move, blend, equalize, gray, transfer -- lets a harness prove which code ran
+double g_secs[7] = {0, 0, 0, 0, 0, 0, 0};  // wall time spent inside each replaced function (host copies included)
+struct Timed {  // counts a call and its wall time
+    int i;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit Timed(int which) : i(which) { ++g_calls[i]; }
+    ~Timed() { g_secs[i] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 void check(int rc, const char* what) {
     if (rc == STITCH_OK) return;
     // The reference signals no errors on this path (degenerate inputs hang or crash it); the drop-in
@@ -50,10 +58,11 @@ void check(int rc, const char* what) {
 // number of times each replaced function has run in this process (0 project, 1 warp, 2 move, 3 blend, 4 equalize, 5 gray,
 // 6 transfer)
 extern "C" int stitch_dropin_call_count(int which) { return which >= 0 && which < 7 ? g_calls[which] : -1; }
+extern "C" double stitch_dropin_seconds(int which) { return which >= 0 && which < 7 ? g_secs[which] : -1.0; }
 
 CImg<unsigned char> Projection::imageProjection(const CImg<unsigned char>& src) {
     if (src.spectrum() != CHANNEL_NUM || src.depth() != 1) throw std::runtime_error("imageProjection: expected a 3-channel 2-D image");
-    ++g_calls[0];
+    const Timed timed(0);
     CImg<unsigned char> res(src.width(), src.height(), 1, src.spectrum());
     check(stitch_project_u8(src.data(), src.width(), src.height(), (float)ANGLE, res.data()), "stitch_project_u8");
     return res;
@@ -70,7 +79,7 @@ unsigned char Projection::bilinearInterpolation(const CImg<unsigned char>&, floa
 // ImageProcess.cpp:27-40 -- the step right after the projection on the same buffer
 CImg<unsigned char> ImageProcess::toGrayScale(const CImg<unsigned char>& src) {
     if (src.spectrum() == 1) return src;  // :29-31
-    ++g_calls[5];
+    const Timed timed(5);
     CImg<unsigned char> gray(src.width(), src.height(), src.depth(), 1);
     check(stitch_gray_u8(src.data(), src.width(), src.height(), gray.data(), nullptr), "stitch_gray_u8");
     return gray;
@@ -79,20 +88,20 @@ CImg<unsigned char> ImageProcess::toGrayScale(const CImg<unsigned char>& src) {
 void ImageProcess::warpingImageByHomography(const CImg<unsigned char>& src, CImg<unsigned char>& dst, Homography& H,
                                             float offset_x, float offset_y) {
     // parameter order of `Homography` (ImageProcess.h:58-73): H00,H01,H02,H10 / H11,H12,H20,H21
-    ++g_calls[1];
+    const Timed timed(1);
     const double p[8] = {H.H[0][0], H.H[0][1], H.H[0][2], H.H[1][0], H.H[1][1], H.H[1][2], H.H[2][0], H.H[2][1]};
     check(stitch_warp_u8(src.data(), src.width(), src.height(), p, offset_x, offset_y, dst.data(), dst.width(), dst.height()),
           "stitch_warp_u8");
 }
 
 void ImageProcess::movingImageByOffset(const CImg<unsigned char>& src, CImg<unsigned char>& dst, int offset_x, int offset_y) {
-    ++g_calls[2];
+    const Timed timed(2);
     check(stitch_move_u8(src.data(), src.width(), src.height(), offset_x, offset_y, dst.data(), dst.width(), dst.height()),
           "stitch_move_u8");
 }
 
 CImg<unsigned char> ImageProcess::blendTwoImages(const CImg<unsigned char>& a, const CImg<unsigned char>& b) {
-    ++g_calls[3];
+    const Timed timed(3);
     CImg<unsigned char> out(a.width(), a.height(), 1, 3);
     check(stitch_blend_u8(a.data(), b.data(), a.width(), a.height(), nullptr, out.data(), nullptr), "stitch_blend_u8");
     return out;
@@ -101,8 +110,10 @@ CImg<unsigned char> ImageProcess::blendTwoImages(const CImg<unsigned char>& a, c
 equalization::equalization(CImg<unsigned char>& src, int mode) {
     switch (mode) {
         case 1:
-            ++g_calls[4];
-            check(stitch_equalize_u8(src.data(), src.width(), src.height(), nullptr), "stitch_equalize_u8");
+            {
+                const Timed timed(4);
+                check(stitch_equalize_u8(src.data(), src.width(), src.height(), nullptr), "stitch_equalize_u8");
+            }
             break;
         case 0:
             // mode 0 of the reference equalises a private grayscale copy and then assigns the untouched colour copy
@@ -118,7 +129,7 @@ equalization::equalization(CImg<unsigned char>& src, int mode) {
 transfer::transfer(CImg<unsigned char>& src, CImg<unsigned char>& tem, CImg<unsigned char>& output) {
     if (src.spectrum() != 3 || tem.spectrum() != 3 || src.depth() != 1 || tem.depth() != 1)
         throw std::runtime_error("transfer: expected 3-channel 2-D images");
-    ++g_calls[6];
+    const Timed timed(6);
     CImg<unsigned char> res(src.width(), src.height(), 1, 3);
     check(stitch_transfer_u8(src.data(), src.width(), src.height(), tem.data(), tem.width(), tem.height(), res.data(), nullptr),
           "stitch_transfer_u8");

@@ -9,7 +9,13 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <list>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "stitch.h"
@@ -647,14 +653,33 @@ int dev_move(const PX* d_src, int sw, int sh, int ox, int oy, PX* d_canvas, int 
     return launch_check("k_move");
 }
 
-// RAII device buffer for the host-pointer entry points
+// RAII device buffer for the host-pointer entry points.  Blocks come from the device's stream-ordered memory pool with its
+// release threshold lifted (once per device), so that a caller that stitches frame after frame -- the reference's matching()
+// loop through the C++ adaptor -- re-uses the same device memory instead of paying hipMalloc + hipFree (both synchronise
+// the device) on every call; stitch_trim() hands the pool's memory back.
+void keep_pool_memory() {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> g(mu);
+    if (done[dev]) return;
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+        uint64_t keep = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
+    done[dev] = true;
+}
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) (void)hipFreeAsync(p, nullptr);
     }
     int alloc(size_t bytes) {
-        HIPCHK(hipMalloc(&p, bytes));
+        keep_pool_memory();
+        HIPCHK(hipMallocAsync(&p, bytes, nullptr));
         return STITCH_OK;
     }
     template <typename T>
@@ -662,6 +687,146 @@ struct DevBuf {
         return static_cast<T*>(p);
     }
 };
+
+// Host <-> device copies of the host-pointer entry points.  The caller's buffers are ordinary pageable memory (CImg's
+// new[]), which the runtime moves at about 10 GB/s through one staging thread -- 70 ms for the 704 MB of a 4096 x 4096
+// float pair, fifty times the blend itself.  Large copies are therefore cut into chunks and spread over a few persistent
+// worker threads, each with its own pair of pinned staging buffers and its own stream: the workers' memcpy()s run side by
+// side and overlap the DMA of earlier chunks.  Small copies go straight through hipMemcpy.
+class HostCopier {
+  public:
+    static HostCopier& get() {
+        static HostCopier* c = new HostCopier();  // never destroyed: its threads are parked on its condition variable until the process ends
+        return *c;
+    }
+    // returns a HIP error code (0 = ok); both calls return when the data has arrived
+    int h2d(void* dev, const void* host, size_t bytes) { return run(static_cast<char*>(dev), const_cast<char*>(static_cast<const char*>(host)), bytes, true); }
+    int d2h(void* host, const void* dev, size_t bytes) { return run(const_cast<char*>(static_cast<const char*>(dev)), static_cast<char*>(host), bytes, false); }
+    void release() {  // stitch_trim(): pinned buffers are given back, the threads stay parked
+        std::lock_guard<std::mutex> g(call_mu_);
+        for (auto& w : workers_)
+            for (auto& b : w->buf)
+                if (b) {
+                    (void)hipHostFree(b);
+                    b = nullptr;
+                }
+    }
+
+  private:
+    static constexpr size_t CHUNK = 8u << 20, DIRECT_BELOW = 4u << 20;
+    struct Worker {
+        std::thread th;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        char* buf[2] = {nullptr, nullptr};
+    };
+    std::vector<Worker*> workers_;
+    std::mutex call_mu_, mu_;  // one copy at a time; job hand-off
+    std::condition_variable cv_, done_cv_;
+    // the current job
+    char *dev_ = nullptr, *host_ = nullptr;
+    size_t bytes_ = 0;
+    bool to_dev_ = true;
+    int device_ = 0, generation_ = 0, pending_ = 0;
+    std::atomic<size_t> next_{0};
+    std::atomic<int> err_{0};
+
+    HostCopier() {
+        int n = 4;
+        if (const char* e = std::getenv("STITCH_COPY_THREADS")) n = std::max(0, std::min(16, atoi(e)));
+        for (int i = 0; i < n; ++i) {
+            Worker* w = new Worker();
+            workers_.push_back(w);
+            w->th = std::thread([this, w] { loop(w); });
+            w->th.detach();  // parked on the condition variable for the life of the process
+        }
+    }
+    int run(char* dev, char* host, size_t bytes, bool to_dev) {
+        if (bytes < DIRECT_BELOW || workers_.empty())
+            return (int)(to_dev ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+        std::lock_guard<std::mutex> call(call_mu_);
+        hipError_t e = hipStreamSynchronize(nullptr);  // the kernels that produced / will consume the device buffer run on the null stream
+        if (e != hipSuccess) return (int)e;
+        if ((e = hipGetDevice(&device_)) != hipSuccess) return (int)e;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            dev_ = dev, host_ = host, bytes_ = bytes, to_dev_ = to_dev;
+            next_ = 0;
+            err_ = 0;
+            pending_ = (int)workers_.size();
+            ++generation_;
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> g(mu_);
+        done_cv_.wait(g, [this] { return pending_ == 0; });
+        return err_.load();
+    }
+    void loop(Worker* w) {
+        int seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return generation_ != seen; });
+                seen = generation_;
+            }
+            work(w);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                --pending_;
+            }
+            done_cv_.notify_all();
+        }
+    }
+    void fail(hipError_t e) {
+        int z = 0;
+        err_.compare_exchange_strong(z, (int)e);
+    }
+    void work(Worker* w) {
+        hipError_t e = hipSetDevice(device_);
+        if (e == hipSuccess && !w->stream) e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+            if (!w->ev[i]) e = hipEventCreateWithFlags(&w->ev[i], hipEventDisableTiming);
+            if (e == hipSuccess && !w->buf[i]) e = hipHostMalloc((void**)&w->buf[i], CHUNK);
+        }
+        if (e != hipSuccess) return fail(e);
+        bool busy[2] = {false, false};
+        size_t off_of[2] = {0, 0}, len_of[2] = {0, 0};
+        int slot = 0;
+        auto drain = [&](int s_) {  // the DMA that last used slot s_ has finished; D2H: its bytes go on to the caller's buffer
+            if (!busy[s_]) return;
+            if ((e = hipEventSynchronize(w->ev[s_])) != hipSuccess) return fail(e);
+            if (!to_dev_) std::memcpy(host_ + off_of[s_], w->buf[s_], len_of[s_]);
+            busy[s_] = false;
+        };
+        for (;;) {
+            const size_t off = next_.fetch_add(CHUNK);
+            if (off >= bytes_ || err_.load()) break;
+            const size_t len = std::min(CHUNK, bytes_ - off);
+            drain(slot);
+            if (to_dev_) {
+                std::memcpy(w->buf[slot], host_ + off, len);
+                e = hipMemcpyAsync(dev_ + off, w->buf[slot], len, hipMemcpyHostToDevice, w->stream);
+            } else
+                e = hipMemcpyAsync(w->buf[slot], dev_ + off, len, hipMemcpyDeviceToHost, w->stream);
+            if (e == hipSuccess) e = hipEventRecord(w->ev[slot], w->stream);
+            if (e != hipSuccess) return fail(e);
+            busy[slot] = true, off_of[slot] = off, len_of[slot] = len;
+            slot ^= 1;
+        }
+        drain(slot);
+        drain(slot ^ 1);
+    }
+};
+#define H2D(dst, src, bytes)                                                                                                   \
+    do {                                                                                                                       \
+        int e_ = HostCopier::get().h2d(dst, src, bytes);                                                                       \
+        if (e_) return fail(STITCH_ERR_HIP, "host-to-device copy of %zu bytes failed: %s", (size_t)(bytes), hipGetErrorString((hipError_t)e_)); \
+    } while (0)
+#define D2H(dst, src, bytes)                                                                                                   \
+    do {                                                                                                                       \
+        int e_ = HostCopier::get().d2h(dst, src, bytes);                                                                       \
+        if (e_) return fail(STITCH_ERR_HIP, "device-to-host copy of %zu bytes failed: %s", (size_t)(bytes), hipGetErrorString((hipError_t)e_)); \
+    } while (0)
 
 template <typename PX>
 int host_project(const PX* src, int w, int h, float fov_deg, PX* dst) {
@@ -671,9 +836,9 @@ int host_project(const PX* src, int w, int h, float fov_deg, PX* dst) {
     const size_t bytes = sizeof(PX) * (size_t)w * h * 3;
     DevBuf s, d;
     if ((rc = s.alloc(bytes)) || (rc = d.alloc(bytes))) return rc;
-    HIPCHK(hipMemcpy(s.p, src, bytes, hipMemcpyHostToDevice));
+    H2D(s.p, src, bytes);
     if ((rc = dev_project<PX>(s.as<PX>(), w, h, fov_deg, d.as<PX>(), nullptr))) return rc;
-    HIPCHK(hipMemcpy(dst, d.p, bytes, hipMemcpyDeviceToHost));
+    D2H(dst, d.p, bytes);
     return STITCH_OK;
 }
 
@@ -685,10 +850,10 @@ int host_warp(const PX* src, int sw, int sh, const double pm[8], float offx, flo
     const size_t sb = sizeof(PX) * (size_t)sw * sh * 3, cb = sizeof(PX) * (size_t)cw * ch * 3;
     DevBuf s, c;
     if ((rc = s.alloc(sb)) || (rc = c.alloc(cb))) return rc;
-    HIPCHK(hipMemcpy(s.p, src, sb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c.p, canvas, cb, hipMemcpyHostToDevice));
+    H2D(s.p, src, sb);
+    H2D(c.p, canvas, cb);
     if ((rc = dev_warp<PX>(s.as<PX>(), sw, sh, pm, offx, offy, c.as<PX>(), cw, ch, nullptr))) return rc;
-    HIPCHK(hipMemcpy(canvas, c.p, cb, hipMemcpyDeviceToHost));
+    D2H(canvas, c.p, cb);
     return STITCH_OK;
 }
 
@@ -700,16 +865,73 @@ int host_move(const PX* src, int sw, int sh, int ox, int oy, PX* canvas, int cw,
     const size_t sb = sizeof(PX) * (size_t)sw * sh * 3, cb = sizeof(PX) * (size_t)cw * ch * 3;
     DevBuf s, c;
     if ((rc = s.alloc(sb)) || (rc = c.alloc(cb))) return rc;
-    HIPCHK(hipMemcpy(s.p, src, sb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c.p, canvas, cb, hipMemcpyHostToDevice));
+    H2D(s.p, src, sb);
+    H2D(c.p, canvas, cb);
     if ((rc = dev_move<PX>(s.as<PX>(), sw, sh, ox, oy, c.as<PX>(), cw, ch, nullptr))) return rc;
-    HIPCHK(hipMemcpy(canvas, c.p, cb, hipMemcpyDeviceToHost));
+    D2H(canvas, c.p, cb);
     return STITCH_OK;
 }
 
-struct PlanGuard {
+// Workspaces of the host-pointer entry points are kept between calls: creating one costs a device allocation of the whole
+// pyramid (1.9 GB at 6144 x 4096), its clearing, the resize tables and two pinned allocations -- more than the blend itself
+// below about 2000 x 2000.  A small LRU keyed by (device, canvas, options) holds idle plans; a call takes one out (so that
+// concurrent callers never share a workspace) and puts it back when it is done.  STITCH_PLAN_CACHE=<n> sets the number of
+// idle plans kept (default 8, 0 = none); stitch_trim() destroys them.
+struct PlanKey {
+    int dev, cw, ch;
+    stitch_blend_opts o;
+    bool operator==(const PlanKey& k) const {
+        return dev == k.dev && cw == k.cw && ch == k.ch && o.sigma == k.o.sigma && o.blur_kind == k.o.blur_kind && o.level_rule == k.o.level_rule &&
+               o.seam_rule == k.o.seam_rule;
+    }
+};
+std::mutex g_plan_mu;
+std::list<std::pair<PlanKey, stitch_plan*>> g_idle_plans;  // most recently used first
+size_t plan_cache_limit() {
+    static const size_t n = [] {
+        const char* e = std::getenv("STITCH_PLAN_CACHE");
+        return e ? (size_t)std::max(0, atoi(e)) : (size_t)8;
+    }();
+    return n;
+}
+struct PlanLease {
     stitch_plan* p = nullptr;
-    ~PlanGuard() { stitch_plan_destroy(p); }
+    PlanKey key{};
+    int acquire(int cw, int ch, const stitch_blend_opts* opts) {
+        stitch_blend_opts o;
+        stitch_blend_opts_default(&o);
+        if (opts) o = *opts;
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        key = PlanKey{dev, cw, ch, o};
+        {
+            std::lock_guard<std::mutex> g(g_plan_mu);
+            for (auto it = g_idle_plans.begin(); it != g_idle_plans.end(); ++it)
+                if (it->first == key) {
+                    p = it->second;
+                    g_idle_plans.erase(it);
+                    return STITCH_OK;
+                }
+        }
+        return stitch_plan_create(cw, ch, opts, &p);
+    }
+    ~PlanLease() {
+        if (!p) return;
+        std::vector<stitch_plan*> evict;
+        {
+            std::lock_guard<std::mutex> g(g_plan_mu);
+            if (plan_cache_limit() > 0 && stitch_plan_clear_fault(p) == STITCH_OK) {  // waits for the plan's last call
+                g_idle_plans.emplace_front(key, p);
+                p = nullptr;
+                while (g_idle_plans.size() > plan_cache_limit()) {
+                    evict.push_back(g_idle_plans.back().second);
+                    g_idle_plans.pop_back();
+                }
+            }
+        }
+        if (p) stitch_plan_destroy(p);
+        for (auto* e : evict) stitch_plan_destroy(e);
+    }
 };
 
 template <typename PX>
@@ -717,16 +939,16 @@ int host_blend(const PX* a, const PX* b, int w, int h, const stitch_blend_opts* 
     int rc = need_device();
     if (rc) return rc;
     if (!a || !b || !out || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "blend: null buffer or bad size %dx%d", w, h);
-    PlanGuard pg;
-    if ((rc = stitch_plan_create(w, h, opts, &pg.p))) return rc;
+    PlanLease pg;
+    if ((rc = pg.acquire(w, h, opts))) return rc;
     const size_t bytes = sizeof(PX) * (size_t)w * h * 3;
     DevBuf da, db, dout;
     if ((rc = da.alloc(bytes)) || (rc = db.alloc(bytes)) || (rc = dout.alloc(bytes))) return rc;
-    HIPCHK(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    H2D(da.p, a, bytes);
+    H2D(db.p, b, bytes);
     if ((rc = dev_blend<PX>(pg.p, da.as<PX>(), db.as<PX>(), dout.as<PX>(), nullptr))) return rc;
     if ((rc = stitch_plan_status(pg.p, seam_out))) return rc;
-    HIPCHK(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    D2H(out, dout.p, bytes);
     return STITCH_OK;
 }
 
@@ -737,18 +959,18 @@ int host_pair(const PX* frame, int fw, int fh, const double pm[8], float offx, f
     if (rc) return rc;
     if (!frame || !mosaic || !out || !pm || fw <= 0 || fh <= 0 || mw <= 0 || mh <= 0 || cw <= 0 || ch <= 0)
         return fail(STITCH_ERR_ARG, "pair: bad argument");
-    PlanGuard pg;
-    if ((rc = stitch_plan_create(cw, ch, opts, &pg.p))) return rc;
+    PlanLease pg;
+    if ((rc = pg.acquire(cw, ch, opts))) return rc;
     const size_t fb = sizeof(PX) * (size_t)fw * fh * 3, mb = sizeof(PX) * (size_t)mw * mh * 3,
                  ob = sizeof(PX) * (size_t)cw * ch * 3;
     DevBuf df, dm, dout;
     if ((rc = df.alloc(fb)) || (rc = dm.alloc(mb)) || (rc = dout.alloc(ob))) return rc;
-    HIPCHK(hipMemcpy(df.p, frame, fb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dm.p, mosaic, mb, hipMemcpyHostToDevice));
+    H2D(df.p, frame, fb);
+    H2D(dm.p, mosaic, mb);
     if ((rc = dev_pair<PX>(pg.p, df.as<PX>(), fw, fh, pm, offx, offy, dm.as<PX>(), mw, mh, ox, oy, dout.as<PX>(), nullptr)))
         return rc;
     if ((rc = stitch_plan_status(pg.p, seam_out))) return rc;
-    HIPCHK(hipMemcpy(out, dout.p, ob, hipMemcpyDeviceToHost));
+    D2H(out, dout.p, ob);
     return STITCH_OK;
 }
 
@@ -821,6 +1043,22 @@ int stitch_set_device(int ordinal) {
     return STITCH_OK;
 }
 
+void stitch_trim(void) {
+    std::vector<stitch_plan*> all;
+    {
+        std::lock_guard<std::mutex> g(g_plan_mu);
+        for (auto& e : g_idle_plans) all.push_back(e.second);
+        g_idle_plans.clear();
+    }
+    for (auto* p : all) stitch_plan_destroy(p);
+    HostCopier::get().release();
+    int dev = 0;
+    hipMemPool_t pool;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
+        (void)hipMemPoolTrimTo(pool, 0);
+    (void)hipGetLastError();
+}
+
 void stitch_blend_opts_default(stitch_blend_opts* o) {
     if (!o) return;
     o->sigma = 2.0f;
@@ -870,10 +1108,10 @@ int stitch_equalize_u8(uint8_t* img, int w, int h, int32_t hist_out[256]) {
     const size_t bytes = (size_t)w * h * 3;
     DevBuf d, dh;
     if ((rc = d.alloc(bytes)) || (rc = dh.alloc(sizeof(int32_t) * 256))) return rc;
-    HIPCHK(hipMemcpy(d.p, img, bytes, hipMemcpyHostToDevice));
+    H2D(d.p, img, bytes);
     if ((rc = dev_equalize_impl(d.as<uint8_t>(), w, h, dh.as<int32_t>(), false, 0, 1, nullptr))) return rc;
-    HIPCHK(hipMemcpy(img, d.p, bytes, hipMemcpyDeviceToHost));
-    if (hist_out) HIPCHK(hipMemcpy(hist_out, dh.p, sizeof(int32_t) * 256, hipMemcpyDeviceToHost));
+    D2H(img, d.p, bytes);
+    if (hist_out) D2H(hist_out, dh.p, sizeof(int32_t) * 256);
     return STITCH_OK;
 }
 
@@ -884,10 +1122,10 @@ int stitch_lummix_u8(uint8_t* result, const uint8_t* equalized, int w, int h, do
     const size_t bytes = (size_t)w * h * 3;
     DevBuf r, e;
     if ((rc = r.alloc(bytes)) || (rc = e.alloc(bytes))) return rc;
-    HIPCHK(hipMemcpy(r.p, result, bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e.p, equalized, bytes, hipMemcpyHostToDevice));
+    H2D(r.p, result, bytes);
+    H2D(e.p, equalized, bytes);
     if ((rc = stitch_dev_lummix_u8(r.as<uint8_t>(), e.as<uint8_t>(), w, h, num, den, nullptr))) return rc;
-    HIPCHK(hipMemcpy(result, r.p, bytes, hipMemcpyDeviceToHost));
+    D2H(result, r.p, bytes);
     return STITCH_OK;
 }
 
@@ -898,10 +1136,10 @@ int stitch_finish_u8(uint8_t* result, int w, int h, double num, double den, int3
     const size_t bytes = (size_t)w * h * 3;
     DevBuf d, dh;
     if ((rc = d.alloc(bytes)) || (rc = dh.alloc(sizeof(int32_t) * 256))) return rc;
-    HIPCHK(hipMemcpy(d.p, result, bytes, hipMemcpyHostToDevice));
+    H2D(d.p, result, bytes);
     if ((rc = dev_equalize_impl(d.as<uint8_t>(), w, h, dh.as<int32_t>(), true, num, den, nullptr))) return rc;
-    HIPCHK(hipMemcpy(result, d.p, bytes, hipMemcpyDeviceToHost));
-    if (hist_out) HIPCHK(hipMemcpy(hist_out, dh.p, sizeof(int32_t) * 256, hipMemcpyDeviceToHost));
+    D2H(result, d.p, bytes);
+    if (hist_out) D2H(hist_out, dh.p, sizeof(int32_t) * 256);
     return STITCH_OK;
 }
 

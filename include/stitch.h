@@ -69,6 +69,10 @@ const char *stitch_last_error(void);
 int stitch_device_count(void);       /* number of HIP devices, 0 if none */
 int stitch_set_device(int ordinal);  /* hipSetDevice for the calling thread */
 void stitch_blend_opts_default(stitch_blend_opts *o);
+/* The host-buffer entry points below keep what they allocate between calls: idle workspaces (plans) in an LRU keyed by
+ * device, canvas size and options (STITCH_PLAN_CACHE=<n> idle plans, default 8, 0 = none) and their device staging
+ * buffers in the device's stream-ordered memory pool.  stitch_trim() releases all of it (current device). */
+void stitch_trim(void);
 /* Pyramid shape for a canvas (ImageProcess.cpp:675-676,705-708).  Returns the level count (>0) or a status;
  * level_w/level_h (capacity 32) may be NULL. */
 int stitch_pyramid_levels(int w, int h, int level_rule, int *level_w, int *level_h);
