@@ -312,6 +312,31 @@ def canvas_bbox(fw, fh, p_fwd, result_w, result_h):
     return mx.value, my.value, nw.value, nh.value
 
 
+class StepGeom(C.Structure):
+    """stitch_step_geom: canvas and offsets of one stitch step (ImageProcess.cpp:206-216, :224)."""
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("cw", C.c_int), ("ch", C.c_int), ("ox", C.c_int), ("oy", C.c_int)]
+
+
+def step_geometry(fw, fh, p_fwd, mw, mh):
+    g = StepGeom()
+    _chk(lib().stitch_step_geometry(int(fw), int(fh), _map8(p_fwd), int(mw), int(mh), C.byref(g)))
+    return g
+
+
+def dev_step(frame, p_fwd, p_bwd, mosaic, opts=None):
+    """One stitch step of matching() from the FORWARD map, device resident (ImageProcess.cpp:206-230): canvas sizing,
+    warp, move, blend -> (new mosaic tensor, StepGeom, Seam)."""
+    import torch
+    frame, mosaic = _timg(frame), _timg(mosaic)
+    g = step_geometry(frame.shape[2], frame.shape[1], p_fwd, mosaic.shape[2], mosaic.shape[1])
+    out = torch.empty((3, g.ch, g.cw), dtype=frame.dtype, device=frame.device)
+    g2, s, o = StepGeom(), Seam(), _opts(opts)
+    _chk(getattr(lib(), "stitch_dev_step_" + _tsfx(frame))(
+        _dp(frame), frame.shape[2], frame.shape[1], _map8(p_fwd), _map8(p_bwd), _dp(mosaic), mosaic.shape[2], mosaic.shape[1], C.byref(o),
+        _dp(out), C.c_size_t(out.numel()), C.byref(g2), C.byref(s), _stream()))
+    return out, g2, s
+
+
 def map_points(x, y, p_fwd, offx, offy):
     """updateFeaturesByHomography (ImageProcess.cpp:622-631) -> (x, y, ix, iy)."""
     x, y = np.array(x, np.float32), np.array(y, np.float32)

@@ -1019,6 +1019,25 @@ int dev_equalize_impl(uint8_t* d_img, int w, int h, int32_t* d_hist_out, bool fu
     return launch_check("equalize");
 }
 
+template <typename PX>
+int dev_step(const PX* d_frame, int fw, int fh, const double p_fwd[8], const double p_bwd[8], const PX* d_mosaic, int mw, int mh,
+                    const stitch_blend_opts* opts, PX* d_out, size_t out_capacity, stitch_step_geom* geom_out, stitch_seam* seam_out,
+                    void* stream) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!d_frame || !d_mosaic || !d_out || !p_fwd || !p_bwd) return fail(STITCH_ERR_ARG, "step: null argument");
+    stitch_step_geom g;
+    if ((rc = stitch_step_geometry(fw, fh, p_fwd, mw, mh, &g))) return rc;
+    if (geom_out) *geom_out = g;
+    if (out_capacity < (size_t)3 * g.cw * g.ch)
+        return fail(STITCH_ERR_ARG, "step: the new mosaic is %d x %d x 3 = %zu samples, the output buffer holds %zu", g.cw, g.ch,
+                    (size_t)3 * g.cw * g.ch, out_capacity);
+    PlanLease lease;  // idle workspace of this canvas size, or a new one; goes back to the cache when the step is done
+    if ((rc = lease.acquire(g.cw, g.ch, opts))) return rc;
+    if ((rc = dev_pair<PX>(lease.p, d_frame, fw, fh, p_bwd, g.min_x, g.min_y, d_mosaic, mw, mh, g.ox, g.oy, d_out, stream))) return rc;
+    return stitch_plan_status(lease.p, seam_out);
+}
+
 }  // namespace
 
 // =========================================== C ABI ==========================================================
@@ -1756,6 +1775,25 @@ int stitch_canvas_bbox(int fw, int fh, const double p_fwd[8], int result_w, int 
     *new_w = (int)std::ceil(mxx - mnx);  // :215 (float subtraction)
     *new_h = (int)std::ceil(mxy - mny);
     return STITCH_OK;
+}
+int stitch_step_geometry(int fw, int fh, const double p_fwd[8], int mw, int mh, stitch_step_geom* g) {
+    if (!g) return fail(STITCH_ERR_ARG, "step_geometry: null output");
+    int rc = stitch_canvas_bbox(fw, fh, p_fwd, mw, mh, &g->min_x, &g->min_y, &g->cw, &g->ch);
+    if (rc) return rc;
+    g->ox = (int)g->min_x;  // movingImageByOffset(result, b, min_x, min_y): float arguments to int parameters (ImageProcess.cpp:224)
+    g->oy = (int)g->min_y;
+    if (g->cw <= 0 || g->ch <= 0) return fail(STITCH_ERR_ARG, "step_geometry: empty canvas %d x %d", g->cw, g->ch);
+    return STITCH_OK;
+}
+int stitch_dev_step_u8(const uint8_t* d_frame, int fw, int fh, const double p_fwd[8], const double p_bwd[8], const uint8_t* d_mosaic, int mw,
+                       int mh, const stitch_blend_opts* opts, uint8_t* d_out, size_t out_capacity, stitch_step_geom* geom_out,
+                       stitch_seam* seam_out, void* stream) {
+    return dev_step<uint8_t>(d_frame, fw, fh, p_fwd, p_bwd, d_mosaic, mw, mh, opts, d_out, out_capacity, geom_out, seam_out, stream);
+}
+int stitch_dev_step_f32(const float* d_frame, int fw, int fh, const double p_fwd[8], const double p_bwd[8], const float* d_mosaic, int mw, int mh,
+                        const stitch_blend_opts* opts, float* d_out, size_t out_capacity, stitch_step_geom* geom_out, stitch_seam* seam_out,
+                        void* stream) {
+    return dev_step<float>(d_frame, fw, fh, p_fwd, p_bwd, d_mosaic, mw, mh, opts, d_out, out_capacity, geom_out, seam_out, stream);
 }
 // updateFeaturesByHomography / updateFeaturesByOffset, ImageProcess.cpp:622-640, on arrays of keypoint coordinates
 int stitch_map_points(float* x, float* y, int32_t* ix, int32_t* iy, int n, const double p_fwd[8], float offx, float offy) {

@@ -264,6 +264,25 @@ int stitch_dev_project_gray_u8(const uint8_t *d_src, int w, int h, float fov_deg
  * the offsets handed to warp (as floats) and move (truncated); new_w x new_h is the canvas.  Host arithmetic. */
 int stitch_canvas_bbox(int fw, int fh, const double p_fwd[8], int result_w, int result_h, float *min_x, float *min_y,
                        int *new_w, int *new_h);
+/* One whole stitch step of matching() (ImageProcess.cpp:206-230) from the FORWARD map, device resident.
+ * stitch_step_geometry is the host arithmetic of :206-216 plus the float -> int truncation of the offsets at :224:
+ * it tells the caller how large the new mosaic is.  stitch_dev_step_* then runs canvas zeroing (:218-219, implicit), warp with
+ * the BACKWARD map and (min_x, min_y) (:222), move by (ox, oy) (:224) and the blend (:230) as one launch sequence on a
+ * workspace taken from the library's plan cache, waits for it and reports the seam outcome like stitch_plan_status.
+ * d_out holds 3 * cw * ch samples (out_capacity = samples available).  The feature updates of :226-227 are
+ * stitch_map_points(p_fwd, min_x, min_y) and stitch_shift_points(ox, oy) below. */
+typedef struct stitch_step_geom {
+    float min_x, min_y; /* <= 0: offsets handed to the warp                                                     */
+    int cw, ch;         /* canvas = size of the new mosaic                                                      */
+    int ox, oy;         /* (int)min_x, (int)min_y: offsets handed to the move                                   */
+} stitch_step_geom;
+int stitch_step_geometry(int fw, int fh, const double p_fwd[8], int mw, int mh, stitch_step_geom *geom);
+int stitch_dev_step_u8(const uint8_t *d_frame, int fw, int fh, const double p_fwd[8], const double p_bwd[8],
+                       const uint8_t *d_mosaic, int mw, int mh, const stitch_blend_opts *opts, uint8_t *d_out,
+                       size_t out_capacity, stitch_step_geom *geom_out, stitch_seam *seam_out, void *stream);
+int stitch_dev_step_f32(const float *d_frame, int fw, int fh, const double p_fwd[8], const double p_bwd[8],
+                        const float *d_mosaic, int mw, int mh, const stitch_blend_opts *opts, float *d_out,
+                        size_t out_capacity, stitch_step_geom *geom_out, stitch_seam *seam_out, void *stream);
 /* updateFeaturesByHomography / updateFeaturesByOffset (ImageProcess.cpp:622-640) on keypoint coordinate arrays
  * (ix/iy = the truncated integer coordinates, optional).  Host arithmetic. */
 int stitch_map_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, const double p_fwd[8], float offx, float offy);

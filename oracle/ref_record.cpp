@@ -11,11 +11,14 @@
 //   ImageProcess::warpingImageByHomography  ImageProcess.cpp:596-606   called at :222
 //   ImageProcess::movingImageByOffset       ImageProcess.cpp:608-620   called at :224
 //   ImageProcess::blendTwoImages            ImageProcess.cpp:648-773   called at :230
+//   ImageProcess::updateFeaturesByHomography ImageProcess.cpp:622-631  called at :226 (logs the FORWARD map of the step,
+//                                            which sizes the canvas at :206-216 and is not seen by the three hooks above)
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -34,6 +37,9 @@ static int g_step = 0;
 typedef void (*warp_fn)(ImageProcess *, const U8Img &, U8Img &, Homography &, float, float);
 typedef void (*move_fn)(ImageProcess *, const U8Img &, U8Img &, int, int);
 typedef U8Img (*blend_fn)(ImageProcess *, const U8Img &, const U8Img &);
+typedef std::map<std::vector<float>, VlSiftKeypoint> FeatMap;
+typedef void (*updh_fn)(ImageProcess *, FeatMap &, Homography &, float, float);
+static updh_fn o_updh;
 static warp_fn o_warp;
 static move_fn o_move;
 static blend_fn o_blend;
@@ -45,7 +51,8 @@ extern "C" __attribute__((visibility("default"))) int rec_init(const char *ref_s
     o_warp = (warp_fn)dlsym(g_ref, "_ZN12ImageProcess24warpingImageByHomographyERKN12cimg_library4CImgIhEERS2_R10Homographyff");
     o_move = (move_fn)dlsym(g_ref, "_ZN12ImageProcess19movingImageByOffsetERKN12cimg_library4CImgIhEERS2_ii");
     o_blend = (blend_fn)dlsym(g_ref, "_ZN12ImageProcess14blendTwoImagesERKN12cimg_library4CImgIhEES4_");
-    if (!o_warp || !o_move || !o_blend) return -2;
+    o_updh = (updh_fn)dlsym(g_ref, "_ZN12ImageProcess26updateFeaturesByHomographyERSt3mapISt6vectorIfSaIfEE15_VlSiftKeypointSt4lessIS3_ESaISt4pairIKS3_S4_EEER10Homographyff");
+    if (!o_warp || !o_move || !o_blend || !o_updh) return -2;
     if (g_log) fclose(g_log);
     g_log = fopen(log_path, "w");
     g_dump_dir = dump_dir ? dump_dir : "";
@@ -88,6 +95,16 @@ void ImageProcess::movingImageByOffset(const U8Img &src, U8Img &dst, int ox, int
     }
     dump("mosaic", src);
     o_move(this, src, dst, ox, oy);
+}
+
+void ImageProcess::updateFeaturesByHomography(FeatMap &feature, Homography &H, float offset_x, float offset_y) {
+    if (g_log) {
+        fprintf(g_log, "fwd step=%d n=%d offx=%.9g offy=%.9g p=", g_step, (int)feature.size(), offset_x, offset_y);
+        const double p[8] = {H.H[0][0], H.H[0][1], H.H[0][2], H.H[1][0], H.H[1][1], H.H[1][2], H.H[2][0], H.H[2][1]};
+        for (int i = 0; i < 8; ++i) fprintf(g_log, "%.17g%s", p[i], i < 7 ? "," : "\n");
+        fflush(g_log);
+    }
+    o_updh(this, feature, H, offset_x, offset_y);
 }
 
 U8Img ImageProcess::blendTwoImages(const U8Img &a, const U8Img &b) {

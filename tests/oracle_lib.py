@@ -13,6 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "libstitch_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_hotpath.so")
+REF6_SO = os.path.join(ROOT, "oracle", "_ref", "libref6_hotpath.so")  # the src/ex6 variant (oracle/ref6_harness.cpp)
 
 
 class BlendOpts(C.Structure):
@@ -287,6 +288,19 @@ class Oracle:
 
 def have_reference():
     return os.path.exists(REF_SO)
+
+
+class ReferenceEx6:
+    """The `src/ex6` variant's own blend (src/ex6/ImageProcess.cpp:638-742, oracle/ref6_harness.cpp)."""
+
+    def __init__(self):
+        self.lib = C.CDLL(REF6_SO)
+
+    def blend(self, a, b):
+        a, b = _img(a, np.uint8), _img(b, np.uint8)
+        out = np.empty_like(a)
+        assert self.lib.ref6_blend_u8(_p(a), _p(b), a.shape[2], a.shape[1], _p(out)) == 0
+        return out
 
 
 class Reference:

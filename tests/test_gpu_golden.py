@@ -1,6 +1,7 @@
 """GPU: the HIP path against the golden vectors the reference produced (tests/golden/), device-resident entry
 points against the oracle, and BASELINE.json's full-size configuration against the oracle (the oracle finishes a
 6144x4096 pair in seconds on the GPU box's host cores, so the full-size check is a direct comparison)."""
+import ctypes as C
 import hashlib
 import json
 import os
@@ -67,6 +68,56 @@ def test_recorded_panorama_chain(st, gpu, J, frames, n):
     from computervisionimagestich2_amd import pipeline
     again = pipeline.stitch_chain([torch.from_numpy(f).to(gpu) for f in frames], run["steps"])
     assert sha(again.cpu().numpy()) == run["final_sha256"]
+
+
+@pytest.mark.parametrize("n", ["2", "4"])
+def test_whole_stitch_step_from_the_forward_map(st, gpu, oracle, J, frames, n):
+    """one device-resident call per stitch step, starting from the FORWARD map the reference's RANSAC
+    produced (recorded, golden.json "p_fwd"): canvas sizing (ImageProcess.cpp:206-216), warp, move, blend, then the feature
+    updates (:226-227).  Canvas, offsets and every intermediate mosaic must be the recorded run's."""
+    import torch
+    from computervisionimagestich2_amd import capi
+    run = J["runs"][n]
+    proj = [capi.dev_project(torch.from_numpy(f).to(gpu)) for f in frames]
+    result = proj[run["steps"][0]["start"]]
+    rng = np.random.default_rng(7)
+    for st_ in run["steps"]:
+        fr = proj[st_["src"]]
+        g = capi.step_geometry(fr.shape[2], fr.shape[1], st_["p_fwd"], result.shape[2], result.shape[1])
+        assert (g.cw, g.ch, g.min_x, g.min_y, g.ox, g.oy) == (st_["cw"], st_["ch"], np.float32(st_["offx"]), np.float32(st_["offy"]), st_["ox"], st_["oy"])
+        result, g2, seam = capi.dev_step(fr, st_["p_fwd"], st_["p"], result)
+        assert (g2.cw, g2.ch, g2.ox, g2.oy) == (g.cw, g.ch, g.ox, g.oy) and list(result.shape) == [3, st_["ch"], st_["cw"]]
+        assert sha(result.cpu().numpy()) == st_["out_sha256"]
+        # the feature updates of the same step, against the oracle (pinned to the reference in test_oracle_vs_reference.py)
+        x, y = rng.uniform(0, fr.shape[2], 50).astype(np.float32), rng.uniform(0, fr.shape[1], 50).astype(np.float32)
+        for a, b in zip(capi.map_points(x, y, st_["p_fwd"], g.min_x, g.min_y), oracle.map_points(x, y, st_["p_fwd"], g.min_x, g.min_y)):
+            assert np.array_equal(a, b)
+        for a, b in zip(capi.shift_points(x, y, g.ox, g.oy), oracle.shift_points(x, y, g.ox, g.oy)):
+            assert np.array_equal(a, b)
+    capi.dev_finish(result, 19.0, 20.0)
+    assert sha(result.cpu().numpy()) == run["final_sha256"]
+    # a buffer that is too small is refused before anything runs
+    small = torch.empty(10, dtype=torch.uint8, device=gpu)
+    rc = capi.lib().stitch_dev_step_u8(capi._dp(proj[0]), 384, 512, capi._map8(run["steps"][0]["p_fwd"]), capi._map8(run["steps"][0]["p"]),
+                                       capi._dp(proj[1]), 384, 512, None, capi._dp(small), C.c_size_t(10), None, None, None)
+    assert rc == capi.ERR_ARG
+
+
+def test_blend_ex6_goldens_on_device(st, gpu, oracle, J):
+    """The src/ex6 variant's whole blend on the HIP path (blur_kind = level_rule = seam_rule = 1) against the bytes the
+    variant's own compiled function produced (golden.json "blend_ex6")."""
+    from oracle_lib import EX6_OPTS
+    for e in J["blend_ex6"]:
+        w, h = e["w"], e["h"]
+        A, B = oracle.synth(w, h, e["fa"]), oracle.synth(w, h, e["fb"])
+        if e["a_left"]:
+            A[:, :, (2 * w) // 3:] = 0
+            B[:, :, : w // 3] = 0
+        else:
+            A[:, :, : w // 3] = 0
+            B[:, :, (2 * w) // 3:] = 0
+        got, _ = st.blend(A, B, EX6_OPTS)
+        assert sha(got) == e["out_sha256"], e
 
 
 def test_blend_synthetic_goldens(st, gpu, oracle, J):

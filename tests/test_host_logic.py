@@ -84,6 +84,18 @@ def test_canvas_bbox_and_feature_updates_are_host_arithmetic(st, oracle):
         assert np.array_equal(a, b)
 
 
+def test_step_geometry_reproduces_the_recorded_canvases(st):
+    """stitch_step_geometry (host arithmetic, no device): forward map + sizes -> canvas, warp offsets, move offsets of every
+    step of the reference's recorded Input/ runs (golden.json, written by the reference build)."""
+    import json
+    J = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")))
+    for n in ("2", "4"):
+        for s_ in J["runs"][n]["steps"]:
+            g = st.capi.step_geometry(s_["fw"], s_["fh"], s_["p_fwd"], s_["mw"], s_["mh"])
+            assert (g.cw, g.ch, g.ox, g.oy) == (s_["cw"], s_["ch"], s_["ox"], s_["oy"])
+            assert g.min_x == np.float32(s_["offx"]) and g.min_y == np.float32(s_["offy"])
+
+
 def test_bmp_header_arithmetic_is_host_only(st, oracle):
     """stitch_bmp_parse / stitch_bmp_file_bytes are host arithmetic on the 54-byte header (CImg.h:48413-48441): they work
     without a GPU and agree with the oracle's parse field by field for every layout knob, and refuse what CImg's 24/32-bit

@@ -288,3 +288,23 @@ def test_integer_luma_bin_is_exact(oracle):
     img = np.stack([R, G, B]).astype(np.uint8).reshape(3, 4096, 4096)
     _, hist, _ = oracle.equalize(img)
     assert np.array_equal(hist, np.bincount(integ.ravel(), minlength=256))
+
+
+def test_blend_ex6_goldens(oracle):
+    """The src/ex6 variant's whole blend (seam_rule = level_rule = blur_kind = 1): the oracle against the bytes the variant's
+    own function produced (golden.json "blend_ex6", tests/golden/add_ex6_goldens.py)."""
+    import hashlib, json
+    from oracle_lib import EX6_OPTS
+    J = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")))
+    assert len(J["blend_ex6"]) >= 10
+    for e in J["blend_ex6"]:
+        w, h = e["w"], e["h"]
+        A, B = oracle.synth(w, h, e["fa"]), oracle.synth(w, h, e["fb"])
+        if e["a_left"]:
+            A[:, :, (2 * w) // 3:] = 0
+            B[:, :, : w // 3] = 0
+        else:
+            A[:, :, : w // 3] = 0
+            B[:, :, (2 * w) // 3:] = 0
+        rc, out, _ = oracle.blend(A, B, EX6_OPTS)
+        assert rc == 0 and hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == e["out_sha256"], e

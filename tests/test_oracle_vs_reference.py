@@ -163,3 +163,54 @@ def test_bmp_load_save(oracle, ref, w, h, tmp_path):
         want = ref.load_bmp_bytes(data, tmp_path)
         assert rc == 0 and got.shape == want.shape and np.array_equal(got, want), kw
     assert oracle.bmp_encode(img) == ref.save_bmp_bytes(img, tmp_path)
+
+
+# ---- the src/ex6 variant of the blend (Deriche blur, depth from min(w,h), three-channel seam scan with double ratios) ----
+def _ex6():
+    import os
+    from oracle_lib import REF6_SO, ReferenceEx6
+    if not os.path.exists(REF6_SO):
+        pytest.skip("oracle/_ref/libref6_hotpath.so not built (needs /root/reference/src/ex6)")
+    return ReferenceEx6()
+
+
+@pytest.mark.parametrize("w,h", [(67, 33), (270, 131), (333, 222), (100, 64), (33, 67), (640, 480), (600, 800)])
+def test_blend_ex6_whole_function(oracle, w, h):
+    """oracle.blend with the variant options against the variant's own ImageProcess::blend
+    (src/ex6/ImageProcess.cpp:638-742, compiled in place): byte for byte, both seam branches."""
+    from oracle_lib import EX6_OPTS
+    ref6 = _ex6()
+    for a_left in (True, False):
+        A, B = oracle.synth(w, h, 21), oracle.synth(w, h, 22)
+        if a_left:
+            A[:, :, (2 * w) // 3:] = 0
+            B[:, :, : w // 3] = 0
+        else:
+            A[:, :, : w // 3] = 0
+            B[:, :, (2 * w) // 3:] = 0
+        rc, out, _ = oracle.blend(A, B, EX6_OPTS)
+        assert rc == 0 and np.array_equal(out, ref6.blend(A, B)), (w, h, a_left)
+
+
+def test_blend_ex6_random_sizes_sweep(oracle):
+    from oracle_lib import EX6_OPTS
+    ref6 = _ex6()
+    rng = np.random.default_rng(99)
+    done = 0
+    while done < 25:
+        w, h = int(rng.integers(4, 260)), int(rng.integers(4, 200))
+        A, B = oracle.synth(w, h, int(rng.integers(0, 50))), oracle.synth(w, h, int(rng.integers(50, 100)))
+        ca, cb = sorted(int(v) for v in rng.integers(0, w + 1, 2))
+        if rng.random() < 0.5:
+            A[:, :, cb:] = 0
+            B[:, :, :ca] = 0
+        else:
+            A[:, :, :ca] = 0
+            B[:, :, cb:] = 0
+        if rng.random() < 0.3:  # a channel that is empty where the others are not: the three-channel "non-empty" rule differs from the root's
+            A[int(rng.integers(0, 3)), :, ca:ca + 5] = 0
+        rc, out, seam = oracle.blend(A, B, EX6_OPTS)
+        if rc != 0:
+            continue  # empty mid row / no overlap / degenerate pyramid: the variant hangs or divides 0/0 there
+        assert np.array_equal(out, ref6.blend(A, B)), (w, h)
+        done += 1
