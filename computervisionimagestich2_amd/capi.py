@@ -536,3 +536,68 @@ class Plan:
         l0 = (C.c_double * len(KERNELS))()
         _chk(lib().stitch_plan_read_profile(self._h, ms, n, l0))
         return {KERNELS[i]: (ms[i], n[i], l0[i]) for i in range(len(KERNELS))}
+
+
+class Band:
+    """stitch_band: this rank's row band of ONE pair split over several GPUs (include/stitch.h, "one pair split into row
+    bands").  Computation only; what crosses ranks is moved by pipeline.BandStitcher."""
+
+    def __init__(self, cw, ch, rank, nranks, split_levels, opts=None):
+        self._h = C.c_void_p()
+        o = _opts(opts)
+        _chk(lib().stitch_band_create(int(cw), int(ch), int(rank), int(nranks), int(split_levels), C.byref(o), C.byref(self._h)))
+        self.cw, self.ch, self.rank, self.nranks, self.split_levels = int(cw), int(ch), int(rank), int(nranks), int(split_levels)
+        tot = C.c_int()
+        lib().stitch_band_levels(self._h, C.byref(tot))
+        self.levels = tot.value
+        self.geom = []
+        for l in range(self.split_levels + 1):
+            g = (C.c_int * 6)()
+            _chk(lib().stitch_band_geometry(self._h, l, g))
+            self.geom.append(dict(w=g[0], rows=g[1], row0=g[2], pitch=g[3], h=g[4], halo=g[5]))
+
+    def close(self):
+        if self._h:
+            lib().stitch_band_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def compose(self, frame, p, offx, offy, mosaic, ox, oy):
+        frame, mosaic = _timg(frame), _timg(mosaic)
+        _chk(getattr(lib(), "stitch_band_compose_" + _tsfx(frame))(
+            self._h, _dp(frame), frame.shape[2], frame.shape[1], _map8(p), C.c_float(offx), C.c_float(offy), _dp(mosaic), mosaic.shape[2],
+            mosaic.shape[1], int(ox), int(oy), _stream()))
+
+    def reduce_x(self, level):
+        _chk(lib().stitch_band_reduce_x(self._h, int(level), _stream()))
+
+    def reduce_y_fwd(self, level, plane, resume, state_out):
+        _chk(lib().stitch_band_reduce_y_fwd(self._h, int(level), int(plane), _dp(resume) if resume is not None else None, _dp(state_out), _stream()))
+
+    def reduce_y_bwd(self, level, plane, fwd_state, resume, state_out):
+        _chk(lib().stitch_band_reduce_y_bwd(self._h, int(level), int(plane), _dp(fwd_state), _dp(resume) if resume is not None else None,
+                                            _dp(state_out), _stream()))
+
+    def rows(self, level, kind, first_row, nrows, buf, to_buffer):
+        assert buf.is_cuda and buf.is_contiguous() and buf.dtype.is_floating_point and buf.element_size() == 4
+        _chk(lib().stitch_band_rows(self._h, int(level), int(kind), int(first_row), int(nrows), _dp(buf), int(bool(to_buffer)), _stream()))
+
+    def top(self, g7):
+        assert g7.is_cuda and g7.is_contiguous()
+        _chk(lib().stitch_band_top(self._h, _dp(g7), _stream()))
+
+    def collapse(self, level, out=None):
+        if level == 0:
+            _chk(getattr(lib(), "stitch_band_collapse_" + _tsfx(out))(self._h, 0, _dp(out), _stream()))
+        else:
+            _chk(lib().stitch_band_collapse_f32(self._h, int(level), None, _stream()))
+
+    def status(self):
+        s = Seam()
+        _chk(lib().stitch_band_status(self._h, C.byref(s)))
+        return s

@@ -144,6 +144,27 @@ void expand_table(int n_src, int n_dst, std::vector<int32_t>& idx, std::vector<d
     }
 }
 
+// The longest run of 256-column blocks in which every group of four columns x0.. has the resize taps s, s+1, s+1, s+2 with
+// s+3 inside the source row (see k_collapse4); [*xa, *xb) empty when there is none or the source level is a single row/column.
+void regular_range(const std::vector<int32_t>& idx, int w, int sw, int sh, int* xa, int* xb) {
+    *xa = *xb = 0;
+    int best_a = 0, best_b = 0, run_a = -1;
+    const int nblk = w / 256;
+    for (int b = 0; b <= nblk; ++b) {
+        bool reg = b < nblk && sw >= 2 && sh >= 2;
+        for (int x0 = b * 256; reg && x0 < (b + 1) * 256; x0 += 4) {
+            const int s_ = idx[x0];
+            reg = idx[x0 + 1] == s_ + 1 && idx[x0 + 2] == s_ + 1 && idx[x0 + 3] == s_ + 2 && s_ + 3 <= sw - 1;
+        }
+        if (reg && run_a < 0) run_a = b;
+        if (!reg && run_a >= 0) {
+            if (b - run_a > best_b - best_a) best_a = run_a, best_b = b;
+            run_a = -1;
+        }
+    }
+    if (best_b > best_a) *xa = best_a * 256, *xb = best_b * 256;
+}
+
 int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
     if (w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "pyramid: non-positive size %dx%d", w, h);
     const int len = level_rule ? (w < h ? w : h) : (w >= h ? w : h);
@@ -228,6 +249,7 @@ struct stitch_plan {
     DRK drk{};
     bool blur_skip = false;
     bool no_fuse = false;  // STITCH_NO_FUSE=1: keep blur and decimation as separate kernels (A/B and tests)
+    bool planes_in = false;  // level 0 (a, b AND the mask plane) is handed in by the caller (the coarse levels of a band-split pair): no seam scan, no implicit mask
     bool profiling = false;
     int prof_only = -1;  // >= 0: record events only around launches of this kernel id
     std::vector<ProfRec> recs;
@@ -340,10 +362,10 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
             dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
             if ((a.w & 1) == 0 && !p->no_fuse) {
-                k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, zt);
+                k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
                 decimated = true;
             } else
-                k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, state_y);
+                k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, state_y, nullptr, nullptr);
         } else if (p->opts.blur_kind == 0) {
             if (do_x) {
                 const int nb = (int)((lines + TS - 1) / TS);
@@ -364,14 +386,14 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
                 {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
-                    k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk);
+                    k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
                 }
                 StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
                 if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
-                    k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{});
+                    k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
                     decimated = true;
                 } else
-                    k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state);
+                    k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, nullptr, nullptr);
             }
         } else {
             HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * np, hipMemcpyDeviceToDevice, s));
@@ -387,7 +409,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
         }
         if (!decimated) {
             StageTimer t(p, s, STITCH_K_DECIMATE, l);
-            k_decimate<<<grid_xy(b.pitch, b.h, np), 256, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, b.g, b.w, b.h, b.pitch, b.ps);
+            k_decimate<<<grid_xy(b.pitch, b.h, np), 256, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, b.g, b.w, b.h, b.pitch, b.ps, 0, 0);
         }
     }
     if (p->wf_levels > 0) HIPCHK(hipMemcpyAsync(p->h_wf_abort, p->wf_ctrl + WF_CTRL_WORDS, sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -426,7 +448,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
         const int nb4 = ((xb - xa) / 4 + WAVE - 1) / WAVE, ncb = (rest + C4_THREADS - 1) / C4_THREADS;
         if (l == 0) {  // level 0: the mask is the seam's step function itself (never read from memory)
             CollapseArgs<OUT, true> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, outs,
-                                      a.w, (size_t)a.w * a.h, p->d_seam, pa, src ? 1 : 0, p->crows_l0, xa, xb};
+                                      a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, p->crows_l0, xa, xb};
             const int strips = (a.h + p->crows_l0 - 1) / p->crows_l0;
             if (xb > xa)
                 k_collapse4<OUT, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
@@ -542,7 +564,7 @@ int dev_pairs(stitch_plan* p, const stitch_pair_desc* d, int n, void* stream) {
             k_src_index<PX><<<grid_xy(a.pitch, (a.h + SI_ROWS - 1) / SI_ROWS, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps, zi);
         }
         else
-            k_compose<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps);
+            k_compose<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps, 0);
     }
     if ((rc = run_seam_mask<PX>(p, n, s, pa, src))) return rc;
     if ((rc = run_reduce<PX>(p, n, s, pa, src, zi))) return rc;
@@ -1330,25 +1352,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         std::vector<int32_t> idx;
         std::vector<double> al;
         expand_table(lw[l + 1], v.w, idx, al);
-        {   // the longest run of 256-column blocks in which every group of four columns x0.. has the taps s, s+1, s+1, s+2
-            // with s+3 inside the source row (see k_collapse4); short levels are left to k_collapse
-            v.c4_xa = v.c4_xb = 0;
-            int best_a = 0, best_b = 0, run_a = -1;
-            const int nblk = v.w / 256;
-            for (int b = 0; b <= nblk; ++b) {
-                bool reg = b < nblk && lw[l + 1] >= 2 && lh[l + 1] >= 2;
-                for (int x0 = b * 256; reg && x0 < (b + 1) * 256; x0 += 4) {
-                    const int s_ = idx[x0];
-                    reg = idx[x0 + 1] == s_ + 1 && idx[x0 + 2] == s_ + 1 && idx[x0 + 3] == s_ + 2 && s_ + 3 <= lw[l + 1] - 1;
-                }
-                if (reg && run_a < 0) run_a = b;
-                if (!reg && run_a >= 0) {
-                    if (b - run_a > best_b - best_a) best_a = run_a, best_b = b;
-                    run_a = -1;
-                }
-            }
-            if (best_b > best_a) v.c4_xa = best_a * 256, v.c4_xb = best_b * 256;
-        }
+        regular_range(idx, v.w, lw[l + 1], lh[l + 1], &v.c4_xa, &v.c4_xb);
         (void)hipMemcpy(v.ix, idx.data(), sizeof(int32_t) * v.w, hipMemcpyHostToDevice);
         (void)hipMemcpy(v.ax, al.data(), sizeof(double) * v.w, hipMemcpyHostToDevice);
         expand_table(lh[l + 1], v.h, idx, al);
@@ -1841,3 +1845,5 @@ int stitch_dev_quantize_u8(const float* d_src, uint8_t* d_dst, size_t n, void* s
 }
 
 }  // extern "C"
+
+#include "stitch_band.inc"

@@ -732,10 +732,11 @@ __global__ __launch_bounds__(256) void k_src_index(PairArgs<PX> pa, float* __res
     }
 }
 
+// row0: canvas row of the planes' row 0 (0 for a whole canvas; the first row of a rank's band when one pair is split over GPUs)
 template <typename PX>
 __global__ __launch_bounds__(256) void k_compose(PairArgs<PX> pa, float* __restrict__ g0_all, int cw, int ch, int pitch,
-                                                 size_t ps) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, pr = blockIdx.z;
+                                                 size_t ps, int row0) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, yl = blockIdx.y, y = yl + row0, pr = blockIdx.z;
     if (x >= pitch) return;
     float* g0 = g0_all + (size_t)pr * 7 * ps;
     float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(256) void k_compose(PairArgs<PX> pa, float* __restr
             for (int c = 0; c < 3; ++c) b[c] = (float)mosaic[so + c * spl];
         }
     }
-    const size_t o = (size_t)y * pitch + x;
+    const size_t o = (size_t)yl * pitch + x;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         g0[o + c * ps] = a[c];
@@ -1369,8 +1370,11 @@ __device__ __forceinline__ f2 y2_step_bwd(Y2& s, const VVK& k, f2 x) {
 // state buffer: [4][planes][pitch] doubles -- v1, v2, v3, iplus of every column
 __device__ __forceinline__ size_t ystate_index(int plane, int pitch, int x) { return (size_t)plane * pitch + x; }
 
+// resume (one pair split into row bands over several GPUs): the rows above this band belong to another rank, which left its
+// recurrence state (v1, v2, v3 per column, [3][planes][pitch]) behind: the sweep continues from it instead of starting at
+// the image's first row.  The state this kernel leaves is exactly what the rank below resumes from.
 __global__ __launch_bounds__(64) void k_vv_y_fwd(float* __restrict__ data, int h, int pitch, size_t ps, VVK k,
-                                                  double* __restrict__ state, MaskL0 mk) {
+                                                  double* __restrict__ state, MaskL0 mk, const double* __restrict__ resume) {
     const int x = (blockIdx.x * WAVE + threadIdx.x) * 2;
     if (x >= pitch) return;
     float* p = data + blockIdx.y * ps + x;
@@ -1383,6 +1387,12 @@ __global__ __launch_bounds__(64) void k_vv_y_fwd(float* __restrict__ data, int h
     Y2 s;
     s.a1 = s.a2 = s.a3 = (double)x0.x / k.sumsq;
     s.b1 = s.b2 = s.b3 = (double)x0.y / k.sumsq;
+    if (resume) {
+        const size_t n = (size_t)gridDim.y * pitch, i = ystate_index(blockIdx.y, pitch, x);
+        s.a1 = resume[i], s.b1 = resume[i + 1];
+        s.a2 = resume[n + i], s.b2 = resume[n + i + 1];
+        s.a3 = resume[2 * n + i], s.b3 = resume[2 * n + i + 1];
+    }
     stream_rows<true>(src, spitch, 0, h, [&](int y, f2 xv) {
         *reinterpret_cast<f2*>(p + (size_t)y * pitch) = y2_step_fwd(s, k, xv);
     });
@@ -1412,18 +1422,40 @@ __device__ __forceinline__ void y2_triggs(const VVK& k, const double* __restrict
 }
 
 // Anticausal y pass, stand-alone (odd source widths): stores the blurred rows in place.
+// resume / state_out: as in k_vv_y_fwd, for the band BELOW (the anticausal sweep runs bottom-up): with `resume` the last row of
+// this band is an ordinary step from the state the rank below left after its first row, not the Triggs boundary value.
+__device__ __forceinline__ void y2_load(const double* __restrict__ st, size_t n, size_t i, Y2& s) {
+    s.a1 = st[i], s.b1 = st[i + 1];
+    s.a2 = st[n + i], s.b2 = st[n + i + 1];
+    s.a3 = st[2 * n + i], s.b3 = st[2 * n + i + 1];
+}
+__device__ __forceinline__ void y2_store(double* __restrict__ st, size_t n, size_t i, const Y2& s) {
+    st[i] = s.a1, st[i + 1] = s.b1;
+    st[n + i] = s.a2, st[n + i + 1] = s.b2;
+    st[2 * n + i] = s.a3, st[2 * n + i + 1] = s.b3;
+}
 __global__ __launch_bounds__(64) void k_vv_y_bwd(float* __restrict__ data, int h, int pitch, size_t ps, VVK k,
-                                                  const double* __restrict__ state) {
+                                                  const double* __restrict__ state, const double* __restrict__ resume,
+                                                  double* __restrict__ state_out) {
     const int x = (blockIdx.x * WAVE + threadIdx.x) * 2;
     if (x >= pitch) return;
     float* p = data + blockIdx.y * ps + x;
+    const size_t n = (size_t)gridDim.y * pitch, i = ystate_index(blockIdx.y, pitch, x);
     Y2 s;
-    f2 first;
-    y2_triggs(k, state, (size_t)gridDim.y * pitch, ystate_index(blockIdx.y, pitch, x), s, first);
-    *reinterpret_cast<f2*>(p + (size_t)(h - 1) * pitch) = first;
-    stream_rows<false>(p, pitch, h - 2, h - 1, [&](int y, f2 xv) {
-        *reinterpret_cast<f2*>(p + (size_t)y * pitch) = y2_step_bwd(s, k, xv);
-    });
+    if (resume) {
+        y2_load(resume, n, i, s);
+        stream_rows<false>(p, pitch, h - 1, h, [&](int y, f2 xv) {
+            *reinterpret_cast<f2*>(p + (size_t)y * pitch) = y2_step_bwd(s, k, xv);
+        });
+    } else {
+        f2 first;
+        y2_triggs(k, state, n, i, s, first);
+        *reinterpret_cast<f2*>(p + (size_t)(h - 1) * pitch) = first;
+        stream_rows<false>(p, pitch, h - 2, h - 1, [&](int y, f2 xv) {
+            *reinterpret_cast<f2*>(p + (size_t)y * pitch) = y2_step_bwd(s, k, xv);
+        });
+    }
+    if (state_out) y2_store(state_out, n, i, s);
 }
 
 // Anticausal y pass fused with the decimation (even source width): the blurred level is never written.
@@ -1439,7 +1471,11 @@ __global__ __launch_bounds__(64) void k_vv_y_bwd(float* __restrict__ data, int h
 // One workgroup barrier per YCH rows hands a slot over.  rc = h-1-y counts rows in processing order.
 __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ data, int w, int h, int pitch, size_t ps,
                                                       VVK k, const double* __restrict__ state, float* __restrict__ dst,
-                                                      int w2, int h2, int dpitch, size_t dps, ZeroTiles zt) {
+                                                      int w2, int h2, int dpitch, size_t dps, ZeroTiles zt,
+                                                      const double* __restrict__ resume, double* __restrict__ state_out, int wh, int wh2) {
+    // wh, wh2: the heights the decimation's overlap weights are taken from (CImg.h:29557-29575 weights by the LEVEL's
+    // heights): h, h2 for a whole level; for a row band of a split pair the level's, not the band's (the quotient is the same
+    // number, but (x*32 + y*32)/64 and (x*96 + y*96)/192 round differently)
     __shared__ __attribute__((aligned(16))) float ring[2][YCH][YCOLS];
     // the wave id is wave-uniform, but anything derived from threadIdx is a lane value to the compiler: readfirstlane
     // keeps the producer/consumer role branches scalar
@@ -1484,7 +1520,12 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
         return zero ? f2{0.f, 0.f} : v;
     };
     if (wave == 0) {
-        if (col_live) y2_triggs(k, state, (size_t)gridDim.y * pitch, ystate_index(blockIdx.y, pitch, x), s, first);
+        if (col_live) {
+            if (resume)
+                y2_load(resume, (size_t)gridDim.y * pitch, ystate_index(blockIdx.y, pitch, x), s);
+            else
+                y2_triggs(k, state, (size_t)gridDim.y * pitch, ystate_index(blockIdx.y, pitch, x), s, first);
+        }
 #pragma unroll
         for (int st = 0; st < YST - 1; ++st) {
             const bool z = chunk_zero(st);
@@ -1493,7 +1534,7 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
         }
     }
     // consumer state: this lane's output column t_x = x/2
-    const float fsx = (float)(unsigned)w2, fw = (float)(unsigned)w, fh = (float)(unsigned)h, fsy = (float)(unsigned)h2;
+    const float fsx = (float)(unsigned)w2, fw = (float)(unsigned)w, fh = (float)(unsigned)wh, fsy = (float)(unsigned)wh2;
     const bool h_odd = (h & 1) != 0;
     const int tx = blockIdx.x * WAVE + lane;
     float* dcol = dst + blockIdx.y * dps + tx;
@@ -1513,7 +1554,7 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
                     for (int u = 0; u < YCH; ++u) {
                         const int rc = j * YCH + u;
                         // sample h-1 takes the Triggs boundary value (CImg.h:34920); rows rc >= h are never read
-                        const f2 o = rc == 0 ? first : y2_step_bwd(s, k, buf[st][u]);
+                        const f2 o = (rc == 0 && !resume) ? first : y2_step_bwd(s, k, buf[st][u]);
                         *reinterpret_cast<f2*>(&ring[st & 1][u][2 * lane]) = o;
                     }
                 }
@@ -1546,6 +1587,7 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
             __syncthreads();
         }
     }
+    if (state_out && wave == 0 && col_live) y2_store(state_out, (size_t)gridDim.y * pitch, ystate_index(blockIdx.y, pitch, x), s);
 }
 
 // ---- fused anticausal-x + causal-y sweep: row bands as pipeline stages ---------------------------------------
@@ -1909,18 +1951,20 @@ __global__ __launch_bounds__(64) void k_deriche(float* __restrict__ data, float*
 // Output t of an axis accumulates, in increasing s, src[s]*(float)d into a float that starts at 0, where d is
 // the overlap of [t*n_src,(t+1)*n_src) with [s*n_dst,(s+1)*n_dst), then divides once by (float)n_src.  x first
 // (result rounded to float), then y -- both inside one work-item, which owns one output sample of one plane.
+// yoff / soff: level row of the destination's / source's row 0 (0 for a whole level; a row band of a split pair passes its
+// first rows, and the LEVEL's heights as h, h2, so that the overlap weights are the level's)
 __global__ __launch_bounds__(256) void k_decimate(const float* __restrict__ src, int w, int h, int spitch, size_t sps,
-                                                  float* __restrict__ dst, int w2, int h2, int dpitch, size_t dps) {
+                                                  float* __restrict__ dst, int w2, int h2, int dpitch, size_t dps, int yoff, int soff) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, pl = blockIdx.z;
     if (x >= dpitch) return;
     float out = 0.f;
     if (x < w2) {
-        const Taps tx = make_taps(x, w, w2), ty = make_taps(y, h, h2);
+        const Taps tx = make_taps(x, w, w2), ty = make_taps(y + yoff, h, h2);
         const float* p = src + pl * sps + tx.s0;
         const float fw = (float)(unsigned)w, fh = (float)(unsigned)h;
         float acc_y = 0.f;
         for (int j = 0; j < ty.n; ++j) {
-            const float* row = p + (size_t)(ty.s0 + j) * spitch;
+            const float* row = p + (size_t)(ty.s0 - soff + j) * spitch;
             float acc = 0.f;
             for (int i = 0; i < tx.n; ++i) acc += row[i] * tx.d[i];
             acc /= fw;

@@ -203,3 +203,124 @@ def batch_order(n_pairs, world):
         for k in range(math.ceil(n_pairs / world)):
             table[(k, r)] = lo + k if lo + k < hi else None
     return table
+
+
+class RankTransport:
+    """What a band-split pair moves between ranks, over torch.distributed.  backend "nccl" (= RCCL over xGMI): device tensors
+    go straight into send/recv/all_gather, ordered on the streams like any other kernel.  staged=True (gloo: the one-GPU
+    test, where every rank drives the same device): tensors are staged through host memory."""
+
+    def __init__(self, group=None, staged=False):
+        import torch.distributed as dist
+        self.dist, self.group, self.staged = dist, group, staged
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def send(self, t, dst):
+        self.dist.send(t.cpu() if self.staged else t, dst, group=self.group)
+
+    def recv(self, t, src):
+        if self.staged:
+            c = t.new_empty(t.shape, device="cpu")
+            self.dist.recv(c, src, group=self.group)
+            t.copy_(c)
+        else:
+            self.dist.recv(t, src, group=self.group)
+        return t
+
+    def all_gather(self, t):
+        import torch
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device="cpu" if self.staged else t.device)
+        self.dist.all_gather_into_tensor(out.flatten(0, 1), t.cpu() if self.staged else t, group=self.group)
+        return out.to(t.device) if self.staged else out
+
+    def swap(self, to_prev, to_next, from_prev, from_next):
+        """Neighbour exchange: to_prev goes to rank-1 (None on rank 0), to_next to rank+1 (None on the last rank); the
+        neighbours' counterparts arrive in from_prev / from_next."""
+        ops, keep = [], []
+        P = self.dist.P2POp
+        for t, peer, fn in ((to_prev, self.rank - 1, self.dist.isend), (to_next, self.rank + 1, self.dist.isend)):
+            if t is not None:
+                c = t.cpu() if self.staged else t
+                keep.append(c)
+                ops.append(P(fn, c, peer, group=self.group))
+        stage = []
+        for t, peer in ((from_prev, self.rank - 1), (from_next, self.rank + 1)):
+            if t is not None:
+                c = t.new_empty(t.shape, device="cpu") if self.staged else t
+                stage.append((t, c))
+                ops.append(P(self.dist.irecv, c, peer, group=self.group))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        if self.staged:
+            for t, c in stage:
+                t.copy_(c)
+
+
+class BandStitcher:
+    """One pair split into row bands over the ranks of a node (BASELINE.json configs[4]; SURVEY.md 8(e)(ii): recurrence
+    state hand-off, not a transpose).  Every rank holds the input frames and calls run() with the same arguments; it gets
+    back ITS band of the mosaic, rows [rank*ch/world, (rank+1)*ch/world).  The per-band computation is capi.Band (HIP
+    kernels); this class only sequences it and moves what crosses ranks through `transport`:
+      * per split level and plane, the causal y sweep waits for 3 doubles per column from the rank above and passes its own
+        on -- the seven planes make the ranks a pipeline -- then the anticausal sweep (+ decimation) the other way round;
+      * the bands of the first replicated level are all-gathered and the coarse levels run on every rank;
+      * before a split level is collapsed, two halo rows of G and E of the level above come from either neighbour."""
+
+    def __init__(self, cw, ch, split_levels, transport, device, opts=None):
+        import torch
+        self.t, self.dev = transport, device
+        self.rank, self.world = transport.rank, transport.world
+        self.band = capi.Band(cw, ch, self.rank, self.world, split_levels, opts)
+        self.Ls, self.geom = split_levels, self.band.geom
+        f64 = dict(dtype=torch.float64, device=device)
+        self.st_f = [[torch.zeros(4 * g["pitch"], **f64) for _ in range(7)] for g in self.geom[:-1]]  # causal state out (+ last row)
+        self.st_b = [[torch.zeros(3 * g["pitch"], **f64) for _ in range(7)] for g in self.geom[:-1]]  # anticausal state out
+        self.res = [[torch.zeros(3 * g["pitch"], **f64) for _ in range(7)] for g in self.geom[:-1]]   # what a neighbour left
+
+    def close(self):
+        self.band.close()
+
+    def run(self, frame, p, offx, offy, mosaic, ox, oy, out=None):
+        import torch
+        B, T, r, N, Ls = self.band, self.t, self.rank, self.world, self.Ls
+        g0 = self.geom[0]
+        if out is None:
+            out = torch.empty((3, g0["rows"], g0["w"]), dtype=frame.dtype, device=self.dev)
+        B.compose(frame, p, offx, offy, mosaic, ox, oy)
+        for l in range(Ls):
+            n3 = 3 * self.geom[l]["pitch"]
+            B.reduce_x(l)
+            for q in range(7):  # causal sweep, rank 0 first
+                res = T.recv(self.res[l][q], r - 1) if r > 0 else None
+                B.reduce_y_fwd(l, q, res, self.st_f[l][q])
+                if r < N - 1:
+                    T.send(self.st_f[l][q][:n3], r + 1)
+            for q in range(7):  # anticausal sweep + decimation, last rank first
+                res = T.recv(self.res[l][q], r + 1) if r < N - 1 else None
+                B.reduce_y_bwd(l, q, self.st_f[l][q], res, self.st_b[l][q])
+                if r > 0:
+                    T.send(self.st_b[l][q], r - 1)
+        # the first replicated level: gather the bands, run the coarse levels on every rank
+        gt = self.geom[Ls]
+        mine = torch.empty((7, gt["rows"], gt["w"]), dtype=torch.float32, device=self.dev)
+        B.rows(Ls, 2, 0, gt["rows"], mine, True)
+        full = T.all_gather(mine).permute(1, 0, 2, 3).reshape(7, N * gt["rows"], gt["w"]).contiguous()
+        B.top(full)
+        for l in range(Ls - 1, -1, -1):
+            if l + 1 < Ls:  # halo rows of the level above: G (a, b) and E, from both neighbours
+                gs = self.geom[l + 1]
+                H, rows, w = gs["halo"], gs["rows"], gs["w"]
+                for kind, planes in ((0, 6), (1, 3)):
+                    mk = lambda: torch.empty((planes, H, w), dtype=torch.float32, device=self.dev)
+                    first, last, above, below = mk(), mk(), mk(), mk()
+                    B.rows(l + 1, kind, 0, H, first, True)
+                    B.rows(l + 1, kind, rows - H, H, last, True)
+                    T.swap(first if r > 0 else None, last if r < N - 1 else None, above if r > 0 else None, below if r < N - 1 else None)
+                    if r > 0:
+                        B.rows(l + 1, kind, -H, H, above, False)
+                    if r < N - 1:
+                        B.rows(l + 1, kind, rows, H, below, False)
+            B.collapse(l, out if l == 0 else None)
+        self.seam = B.status()
+        return out

@@ -288,6 +288,44 @@ int stitch_dev_step_f32(const float *d_frame, int fw, int fh, const double p_fwd
 int stitch_map_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, const double p_fwd[8], float offx, float offy);
 int stitch_shift_points(float *x, float *y, int32_t *ix, int32_t *iy, int n, int ox, int oy);
 
+/* ---- one pair split into row bands over several GPUs (BASELINE.json configs[4]; SURVEY.md 8(e), state hand-off) ----------
+ * Rank r of nranks owns rows [r*h_l/nranks, (r+1)*h_l/nranks) of every SPLIT level l < split_levels of the blend's pyramids
+ * (band heights must be even); the levels from split_levels up are replicated on every rank.  This library does the
+ * per-band computation; the caller moves what crosses ranks (computervisionimagestich2_amd/pipeline.py: BandStitcher over
+ * torch.distributed -- RCCL send/recv over xGMI, or gloo staged through the host in the one-GPU test):
+ *   compose (S1 + seam + mask, every rank from the full input frames)
+ *   per split level l:  reduce_x;  per plane 0..6: reduce_y_fwd (resume state from the rank above, leaves the state for the
+ *                       rank below), then per plane: reduce_y_bwd (resume from the rank below; writes this rank's band of level l+1)
+ *   all-gather of the bands of level split_levels (stitch_band_rows kind 2) -> stitch_band_top (replicated coarse levels)
+ *   per split level, coarse to fine: halo rows of G and E of level l+1 from both neighbours (stitch_band_rows), collapse.
+ * Results equal the single-GPU path (and the oracle) bit for bit.  Root variant options only. */
+typedef struct stitch_band stitch_band;
+int stitch_band_create(int cw, int ch, int rank, int nranks, int split_levels, const stitch_blend_opts *opts, stitch_band **band_out);
+void stitch_band_destroy(stitch_band *band);
+/* out[6] = {w, rows, row0, pitch, rows of the whole level, halo} of level 0..split_levels */
+int stitch_band_geometry(const stitch_band *band, int level, int out[6]);
+int stitch_band_levels(const stitch_band *band, int *total_levels); /* returns split_levels */
+int stitch_band_compose_u8(stitch_band *band, const uint8_t *d_frame, int fw, int fh, const double p[8], float offx, float offy,
+                           const uint8_t *d_mosaic, int mw, int mh, int ox, int oy, void *stream);
+int stitch_band_compose_f32(stitch_band *band, const float *d_frame, int fw, int fh, const double p[8], float offx, float offy,
+                            const float *d_mosaic, int mw, int mh, int ox, int oy, void *stream);
+int stitch_band_reduce_x(stitch_band *band, int level, void *stream);
+/* resume: [3][pitch] doubles from the rank above (NULL exactly on rank 0); state_out: [4][pitch] doubles */
+int stitch_band_reduce_y_fwd(stitch_band *band, int level, int plane, const double *d_resume, double *d_state_out, void *stream);
+/* fwd_state: this plane's reduce_y_fwd state_out; resume: [3][pitch] from the rank below (NULL exactly on the last rank);
+ * state_out: [3][pitch] for the rank above */
+int stitch_band_reduce_y_bwd(stitch_band *band, int level, int plane, const double *d_fwd_state, const double *d_resume,
+                             double *d_state_out, void *stream);
+/* band rows <-> dense buffer [planes][nrows][w]; kind 0: G a,b (6 planes), 1: E (3), 2: G + mask (7); first_row band-local,
+ * -halo .. rows+halo-1; to_buffer != 0 packs, 0 unpacks */
+int stitch_band_rows(stitch_band *band, int level, int kind, int first_row, int nrows, float *d_buf, int to_buffer, void *stream);
+/* d_g7: level split_levels, all rows, 7 dense planes [a0 a1 a2 b0 b1 b2 m][h][w] */
+int stitch_band_top(stitch_band *band, const float *d_g7, void *stream);
+/* level 0 writes this rank's band of the mosaic, dense [3][rows][cw]; other levels ignore d_out_band */
+int stitch_band_collapse_u8(stitch_band *band, int level, uint8_t *d_out_band, void *stream);
+int stitch_band_collapse_f32(stitch_band *band, int level, float *d_out_band, void *stream);
+int stitch_band_status(stitch_band *band, stitch_seam *seam_out);
+
 /* Deterministic synthetic frames of the benchmark configs: values 1..250, never 0 ("empty" to
  * the seam scan); the float twin adds a 16-bit fraction.  Same generator as oracle_synth_* (tests compare). */
 int stitch_dev_synth_u8(uint8_t *d_dst, int w, int h, int frame_id, void *stream);

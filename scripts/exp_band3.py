@@ -1,0 +1,54 @@
+"""N bands of one pair as N THREADS of one process (queues instead of torch.distributed): full BandStitcher.run, fused and
+plain anticausal sweep, two repetitions, against the oracle."""
+import os, sys, threading, queue
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from computervisionimagestich2_amd import pipeline
+from oracle_lib import Oracle
+O = Oracle(); dev = torch.device("cuda:0")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+cw = int(sys.argv[2]) if len(sys.argv) > 2 else 768
+fw, fh, ch, Ls = 520, 384, 384, 2
+
+class QT:
+    def __init__(self, rank, world, qs, bar): self.rank, self.world, self.qs, self.bar = rank, world, qs, bar
+    def _c(self, t):
+        c = t.clone(); torch.cuda.current_stream().synchronize(); return c
+    def send(self, t, dst): self.qs[(self.rank, dst)].put(self._c(t))
+    def recv(self, t, src): t.copy_(self.qs[(src, self.rank)].get()); return t
+    def all_gather(self, t):
+        for d in range(self.world):
+            if d != self.rank: self.qs[(self.rank, d)].put(("ag", self._c(t)))
+        parts = [None] * self.world
+        parts[self.rank] = t
+        for s in range(self.world):
+            if s != self.rank:
+                tag, v = self.qs[(s, self.rank)].get(); assert tag == "ag"; parts[s] = v
+        return torch.stack(parts)
+    def swap(self, to_prev, to_next, from_prev, from_next):
+        if to_prev is not None: self.qs[(self.rank, self.rank - 1)].put(self._c(to_prev))
+        if to_next is not None: self.qs[(self.rank, self.rank + 1)].put(self._c(to_next))
+        if from_prev is not None: from_prev.copy_(self.qs[(self.rank - 1, self.rank)].get())
+        if from_next is not None: from_next.copy_(self.qs[(self.rank + 1, self.rank)].get())
+
+A, B = O.synth(fw, fh, 4, np.uint8), O.synth(fw, fh, 5, np.uint8)
+P = [1.0, 0.002, 1e-6, -(fw // 2) - 40.0, -0.001, 1.0, 5e-7, 1.5]
+rc, ref = O.pair(B, P, 0.0, 0.0, A, 0, 0, cw, ch)
+for plain in (False, True):
+    if plain: os.environ["STITCH_BAND_PLAIN"] = "1"
+    else: os.environ.pop("STITCH_BAND_PLAIN", None)
+    qs = {(a, b): queue.Queue() for a in range(N) for b in range(N) if a != b}
+    outs = [[None, None] for _ in range(N)]
+    def work(r):
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            bs = pipeline.BandStitcher(cw, ch, Ls, QT(r, N, qs, None), dev)
+            for rep in range(2):
+                outs[r][rep] = bs.run(torch.from_numpy(B).to(dev), P, 0.0, 0.0, torch.from_numpy(A).to(dev), 0, 0).cpu().numpy()
+            bs.close()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(N)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for rep in range(2):
+        got = np.concatenate([outs[r][rep] for r in range(N)], axis=1)
+        bad = np.argwhere(got != ref)
+        print("plain" if plain else "fused", "rep", rep, "bad", len(bad), bad[:4].tolist())
