@@ -10,7 +10,8 @@ pairs on batched plans, up to --streams (4) sequences in flight on separate HIP 
 host synchronisation between them.  Frames are generated on the device before the timed region: every input is
 resident in HBM when timing starts.
 
-N > 1: every finished mosaic is cast to unsigned char (the reference's own output type, CImg<unsigned char>) and the
+N > 1: every finished mosaic also leaves the level-0 collapse as unsigned char (the reference's own output type,
+CImg<unsigned char>; `out_u8` of the pair descriptor) and the
 step's 32 mosaics are all-gathered (RCCL over xGMI, asynchronously, overlapping the next step's kernels) so that every
 rank ends up holding the whole batch -- the one exchange the path has, INSIDE the timed region; `value` includes it and
 `config.no_exchange_mpix_s` gives the same run without it.  N = 1: the rank already holds the batch, no exchange.
@@ -190,16 +191,19 @@ def main():
         idx = list(range(seq[0], seq[1]))[:n]
         with torch.cuda.stream(L["stream"]):
             outs = L["outs"][slot]
-            L["plan"].pairs([pair_in[i] + (outs[q],) for q, i in enumerate(idx)])
+            if gather_step is None:
+                L["plan"].pairs([pair_in[i] + (outs[q],) for q, i in enumerate(idx)])
+            else:
+                blk = gather.input_slot(gather_step)  # waits (on this stream) for the gather that last used the buffers
+                if tdt == torch.float32:  # the unsigned char copy that travels is written by the level-0 collapse itself (out_u8)
+                    L["plan"].pairs([pair_in[i] + (outs[q], blk[i - lo]) for q, i in enumerate(idx)])
+                else:
+                    L["plan"].pairs([pair_in[i] + (outs[q],) for q, i in enumerate(idx)])
+                    for q, i in enumerate(idx):
+                        blk[i - lo].copy_(outs[q])
             L["holds"][slot] = idx
             L["last"] = slot
             if gather_step is not None:
-                blk = gather.input_slot(gather_step)  # waits (on this stream) for the gather that last used the buffers
-                for q, i in enumerate(idx):
-                    if tdt == torch.float32:
-                        capi.dev_quantize(outs[q], blk[i - lo])
-                    else:
-                        blk[i - lo].copy_(outs[q])
                 ev = torch.cuda.Event()
                 ev.record(L["stream"])
                 return ev

@@ -55,7 +55,7 @@ class PairDesc(C.Structure):
     """stitch_pair_desc: one independent stitch step of a batch (device pointers)."""
     _fields_ = [("frame", C.c_void_p), ("fw", C.c_int), ("fh", C.c_int), ("p", C.c_double * 8), ("offx", C.c_float),
                 ("offy", C.c_float), ("mosaic", C.c_void_p), ("mw", C.c_int), ("mh", C.c_int), ("ox", C.c_int), ("oy", C.c_int),
-                ("out", C.c_void_p)]
+                ("out", C.c_void_p), ("out_u8", C.c_void_p)]
 
 
 _lib = None
@@ -492,11 +492,14 @@ class Plan:
 
     def pairs(self, items):
         """Enqueue n <= max_pairs independent pairs as ONE launch sequence.  items: iterable of
-        (frame, p, offx, offy, mosaic, ox, oy, out) with device tensors; returns the list of `out` tensors."""
+        (frame, p, offx, offy, mosaic, ox, oy, out[, out_u8]) with device tensors; out_u8 (float frames only) receives the
+        mosaic as unsigned char as well.  Returns the list of `out` tensors."""
         items = list(items)
         arr = (PairDesc * len(items))()
         sfx = None
-        for d, (frame, p, offx, offy, mosaic, ox, oy, out) in zip(arr, items):
+        for d, it in zip(arr, items):
+            frame, p, offx, offy, mosaic, ox, oy, out = it[:8]
+            out8 = it[8] if len(it) > 8 else None
             frame, mosaic, out = _timg(frame), _timg(mosaic), _timg(out)
             assert tuple(out.shape) == (3, self.ch, self.cw) and out.dtype == frame.dtype == mosaic.dtype
             sfx = _tsfx(frame) if sfx is None else sfx
@@ -506,6 +509,10 @@ class Plan:
             d.offx, d.offy = float(offx), float(offy)
             d.mosaic, d.mw, d.mh = mosaic.data_ptr(), mosaic.shape[2], mosaic.shape[1]
             d.ox, d.oy, d.out = int(ox), int(oy), out.data_ptr()
+            if out8 is not None:
+                import torch
+                assert out8.is_cuda and out8.is_contiguous() and out8.dtype == torch.uint8 and tuple(out8.shape) == (3, self.ch, self.cw)
+                d.out_u8 = out8.data_ptr()
         _chk(getattr(lib(), "stitch_dev_pairs_" + sfx)(self._h, arr, len(items), _stream()))
         return [it[7] for it in items]
 

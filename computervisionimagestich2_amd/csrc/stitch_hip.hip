@@ -441,7 +441,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
         if (p->collapse4) xa = a.c4_xa, xb = a.c4_xb;
         if (l == 0) {
             bool ok = (a.w % 4) == 0;
-            for (int i = 0; i < n; ++i) ok = ok && (reinterpret_cast<uintptr_t>(outs.p[i]) % (4 * sizeof(OUT))) == 0;
+            for (int i = 0; i < n; ++i) ok = ok && (reinterpret_cast<uintptr_t>(outs.p[i]) % (4 * sizeof(OUT))) == 0 && (reinterpret_cast<uintptr_t>(outs.q[i]) % 4) == 0;
             if (!ok) xa = xb = 0;
         }
         const int cols = l == 0 ? a.w : a.pitch, rest = cols - (xb - xa);
@@ -533,6 +533,8 @@ int dev_pairs(stitch_plan* p, const stitch_pair_desc* d, int n, void* stream) {
         pa.mosaic[i] = static_cast<const PX*>(d[i].mosaic);
         pa.out[i] = static_cast<PX*>(d[i].out);
         outs.p[i] = pa.out[i];
+        outs.q[i] = sizeof(PX) == 4 ? static_cast<uint8_t*>(d[i].out_u8) : nullptr;
+        if (sizeof(PX) == 1 && d[i].out_u8) return fail(STITCH_ERR_ARG, "pairs: out_u8 is for float frames (descriptor %d)", i);
         std::memcpy(pa.map[i].p, d[i].p, sizeof pa.map[i].p);
         pa.fw[i] = d[i].fw;
         pa.fh[i] = d[i].fh;

@@ -2047,6 +2047,8 @@ __global__ __launch_bounds__(256) void k_blend_top(const float* __restrict__ g_a
 template <typename OUT>
 struct OutPtrs {
     OUT* p[MAXB];
+    uint8_t* q[MAXB];  // optional second copy of a float mosaic as unsigned char (the reference's own output type,
+                       // CImg<unsigned char>(CImg<float>): C-cast truncation), written by the level-0 collapse; nullptr = none
 };
 // One work-item owns one column of a strip of CROWS output rows.  EXPAND's x pass depends only on the source row,
 // and consecutive output rows share their source rows (iy advances by at most one per output row when
@@ -2175,9 +2177,10 @@ __device__ __forceinline__ void collapse_cols1(const CollapseArgs<OUT, DENSE>& A
                 v = 255.f;
             else if (v < 0.f)
                 v = 0.f;
-            if (DENSE)  // the finished mosaic is not read again by this sequence
+            if (DENSE) {  // the finished mosaic is not read again by this sequence
                 __builtin_nontemporal_store(px_store<OUT>(v), &out[(size_t)y * opitch + x + c * ops]);
-            else
+                if (sizeof(OUT) == 4 && A.outs.q[pr]) A.outs.q[pr][(size_t)y * opitch + x + c * ops] = px_store<uint8_t>(v);
+            } else
                 out[(size_t)y * opitch + x + c * ops] = px_store<OUT>(v);
         }
     }
@@ -2312,6 +2315,7 @@ __device__ __forceinline__ void collapse_cols4(const CollapseArgs<OUT, DENSE>& A
     const float* sb = sa + 3 * sps;
     const float* se = A.en_all + ((size_t)pr * 3 + c) * sps;
     OUT* __restrict__ out = (DENSE ? A.outs.p[pr] : A.outs.p[0] + (size_t)pr * 3 * ops) + c * ops;
+    uint8_t* __restrict__ out8 = DENSE && A.outs.q[pr] ? A.outs.q[pr] + c * ops : nullptr;
     const bool use_src = DENSE && A.use_src;
     // table entries of the four columns; their taps are samples s0 .. s0+3 of a source row
     const int s0 = tb.ix[x0];
@@ -2420,7 +2424,10 @@ __device__ __forceinline__ void collapse_cols4(const CollapseArgs<OUT, DENSE>& A
             v4[j] = v;
         }
         if constexpr (DENSE)
+        {
             store4<OUT>(&out[(size_t)y * opitch + x0], v4);
+            if (sizeof(OUT) == 4 && out8) store4<uint8_t>(&out8[(size_t)y * opitch + x0], v4);
+        }
         else
             *reinterpret_cast<f4*>(&out[(size_t)y * opitch + x0]) = f4{v4[0], v4[1], v4[2], v4[3]};
     }

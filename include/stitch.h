@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STITCH_ABI_VERSION 1
+#define STITCH_ABI_VERSION 2
 
 typedef enum stitch_status {
     STITCH_OK = 0,
@@ -177,6 +177,9 @@ typedef struct stitch_pair_desc {
     int mw, mh;
     int ox, oy;         /* integer offsets as passed to movingImageByOffset                                     */
     void *out;
+    void *out_u8;       /* _f32 calls only, optional (NULL = none): a second copy of the mosaic as unsigned char --
+                           the reference's own output type, CImg<unsigned char>(CImg<float>), C-cast truncation
+                           (ImageProcess.cpp:772) -- written by the same kernel (what a sharded batch gathers)       */
 } stitch_pair_desc;
 int stitch_dev_pairs_u8(stitch_plan *plan, const stitch_pair_desc *pairs, int n, void *stream);
 int stitch_dev_pairs_f32(stitch_plan *plan, const stitch_pair_desc *pairs, int n, void *stream);

@@ -270,6 +270,29 @@ def test_batched_plan_matches_single_pairs(st, gpu, oracle, dtype, n):
     plan.close()
 
 
+def test_uint8_copy_of_float_mosaics(st, gpu, oracle):
+    """stitch_pair_desc.out_u8: the level-0 collapse writes the float mosaic and, in the same pass, its unsigned char cast
+    (CImg<unsigned char>(CImg<float>), truncation) -- what a sharded batch gathers; both collapse kernels (a canvas width that
+    is a multiple of 4 and one that is not)."""
+    import torch
+    from computervisionimagestich2_amd import capi
+    for (fw, fh, cw, ch) in [(704, 512, 1024, 512), (520, 384, 770, 384)]:
+        plan = capi.Plan(cw, ch, max_pairs=2)
+        items = []
+        for i in range(2):
+            A, B = oracle.synth(fw, fh, 2 * i, np.float32), oracle.synth(fw, fh, 2 * i + 1, np.float32)
+            P = [1.0, 0.002, 1e-6, -(fw // 2) - 20.0 - 8.0 * i, -0.001, 1.0, 5e-7, 1.5]
+            items.append((torch.from_numpy(B).to(gpu), P, 0.0, 0.0, torch.from_numpy(A).to(gpu), 0, 0,
+                          torch.empty((3, ch, cw), dtype=torch.float32, device=gpu), torch.full((3, ch, cw), 7, dtype=torch.uint8, device=gpu)))
+        plan.pairs(items)
+        for q, it in enumerate(items):
+            plan.status(q)
+            rc, ref = oracle.pair(it[0].cpu().numpy(), it[1], 0.0, 0.0, it[4].cpu().numpy(), 0, 0, cw, ch)
+            assert rc == 0 and np.array_equal(it[7].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+            assert np.array_equal(it[8].cpu().numpy(), ref.astype(np.uint8)) and torch.equal(it[8], capi.dev_quantize(it[7]))
+        plan.close()
+
+
 def test_config5_size_single_gpu_against_oracle(st, gpu, oracle):
     """BASELINE.json configs[4]'s problem size (one 16384x16384x3 f32 pair -> 24576x16384 canvas, 14 levels) on ONE
     GPU ("replicas only" for the multi-GPU form): the 30 GB plan fits HBM; compared in full with the
