@@ -25,7 +25,8 @@ GROUP = {"k_compose": "compose", "k_src_index": "compose", "k_seam": "seam", "k_
          "k_vv_x_fwd<unsigned char, true>": "vv_x_fwd",
          "k_vv_x_bwd": "vv_x_bwd", "k_vv_y_fwd": "vv_y_fwd", "k_vv_y_bwd_dec": "vv_y_bwd", "k_vv_y_bwd": "vv_y_bwd",
          "k_decimate": "decimate", "k_collapse<float, false>": "collapse", "k_collapse<float, true>": "collapse_l0",
-         "k_collapse<unsigned char, true>": "collapse_l0", "k_blend_top": "collapse_top", "k_vv_xbyf<false>": "vv_xbyf",
+         "k_collapse<unsigned char, true>": "collapse_l0", "k_collapse4<float, false>": "collapse", "k_collapse4<float, true>": "collapse_l0",
+         "k_collapse4<unsigned char, true>": "collapse_l0", "k_blend_top": "collapse_top", "k_vv_xbyf<false>": "vv_xbyf",
          "k_vv_xbyf<true>": "vv_xbyf"}
 LAUNCH_GROUPS = {"compose": 1, "seam": 1, "mask": 1, "vv_x_fwd": 11, "vv_x_bwd": 9, "vv_y_fwd": 9, "vv_y_bwd": 11, "decimate": 0,
                  "collapse_top": 1, "collapse": 10, "collapse_l0": 1, "vv_xbyf": 2}  # config 2 with two fused-sweep levels
@@ -36,7 +37,7 @@ def kname(full):
     s = s[s.index("sk::") + 4:] if "sk::" in s else s
     if "(" in s:
         s = s[: s.index("(")]
-    if s.startswith("k_collapse<") or s.startswith("k_vv_xbyf<") or s.startswith("k_vv_x_fwd<"):
+    if s.startswith("k_collapse<") or s.startswith("k_collapse4<") or s.startswith("k_vv_xbyf<") or s.startswith("k_vv_x_fwd<"):
         return s
     return s[: s.index("<")] if "<" in s else s
 
