@@ -262,8 +262,8 @@ class BandStitcher:
     state hand-off, not a transpose).  Every rank holds the input frames and calls run() with the same arguments; it gets
     back ITS band of the mosaic, rows [rank*ch/world, (rank+1)*ch/world).  The per-band computation is capi.Band (HIP
     kernels); this class only sequences it and moves what crosses ranks through `transport`:
-      * per split level and plane, the causal y sweep waits for 3 doubles per column from the rank above and passes its own
-        on -- the seven planes make the ranks a pipeline -- then the anticausal sweep (+ decimation) the other way round;
+      * per split level, the causal y sweep waits for 3 doubles per column and plane from the rank above and passes its own
+        on, then the anticausal sweep (+ decimation) the other way round;
       * the bands of the first replicated level are all-gathered and the coarse levels run on every rank;
       * before a split level is collapsed, two halo rows of G and E of the level above come from either neighbour."""
 
@@ -274,9 +274,10 @@ class BandStitcher:
         self.band = capi.Band(cw, ch, self.rank, self.world, split_levels, opts)
         self.Ls, self.geom = split_levels, self.band.geom
         f64 = dict(dtype=torch.float64, device=device)
-        self.st_f = [[torch.zeros(4 * g["pitch"], **f64) for _ in range(7)] for g in self.geom[:-1]]  # causal state out (+ last row)
-        self.st_b = [[torch.zeros(3 * g["pitch"], **f64) for _ in range(7)] for g in self.geom[:-1]]  # anticausal state out
-        self.res = [[torch.zeros(3 * g["pitch"], **f64) for _ in range(7)] for g in self.geom[:-1]]   # what a neighbour left
+        # recurrence states of all seven planes, [k][7][pitch] doubles per split level
+        self.st_f = [torch.zeros(4 * 7 * g["pitch"], **f64) for g in self.geom[:-1]]  # causal state out (+ the band's last row)
+        self.st_b = [torch.zeros(3 * 7 * g["pitch"], **f64) for g in self.geom[:-1]]  # anticausal state out
+        self.res = [torch.zeros(3 * 7 * g["pitch"], **f64) for g in self.geom[:-1]]   # what a neighbour left
 
     def close(self):
         self.band.close()
@@ -289,18 +290,18 @@ class BandStitcher:
             out = torch.empty((3, g0["rows"], g0["w"]), dtype=frame.dtype, device=self.dev)
         B.compose(frame, p, offx, offy, mosaic, ox, oy)
         for l in range(Ls):
-            n3 = 3 * self.geom[l]["pitch"]
+            n3 = 3 * 7 * self.geom[l]["pitch"]
             B.reduce_x(l)
-            for q in range(7):  # causal sweep, rank 0 first
-                res = T.recv(self.res[l][q], r - 1) if r > 0 else None
-                B.reduce_y_fwd(l, q, res, self.st_f[l][q])
-                if r < N - 1:
-                    T.send(self.st_f[l][q][:n3], r + 1)
-            for q in range(7):  # anticausal sweep + decimation, last rank first
-                res = T.recv(self.res[l][q], r + 1) if r < N - 1 else None
-                B.reduce_y_bwd(l, q, self.st_f[l][q], res, self.st_b[l][q])
-                if r > 0:
-                    T.send(self.st_b[l][q], r - 1)
+            # causal sweep, rank 0 first; then the anticausal sweep + decimation, last rank first.  A band's sweep is one chain
+            # of dependent rows -- as long for seven planes as for one -- so all planes go in one launch and one message
+            res = T.recv(self.res[l], r - 1) if r > 0 else None
+            B.reduce_y_fwd(l, -1, res, self.st_f[l])
+            if r < N - 1:
+                T.send(self.st_f[l][:n3], r + 1)
+            res = T.recv(self.res[l], r + 1) if r < N - 1 else None
+            B.reduce_y_bwd(l, -1, self.st_f[l], res, self.st_b[l])
+            if r > 0:
+                T.send(self.st_b[l], r - 1)
         # the first replicated level: gather the bands, run the coarse levels on every rank
         gt = self.geom[Ls]
         mine = torch.empty((7, gt["rows"], gt["w"]), dtype=torch.float32, device=self.dev)

@@ -91,11 +91,26 @@ class Oracle:
         L.oracle_equalize_u8.restype = C.c_int
         L.oracle_lummix_u8.restype = C.c_int
 
+        # OpenMP's thread count is a per-thread setting that defaults to every CPU the machine has (256 on the GPU box, whose
+        # share is 16 cores: an 18 s pair instead of 0.3 s) and that other libraries in the process change; the wrapper
+        # therefore sets it, in the calling thread, before every parallel entry point
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        self._n = max(1, min(avail, int(os.environ.get("STITCH_CPU_THREADS", "16"))))
+
     def threads(self):
         return self.lib.oracle_threads()
 
     def set_threads(self, n):
+        self._n = int(n)
         self.lib.oracle_set_threads(C.c_int(n))
+
+    def __getattribute__(self, name):
+        if name in ("project", "warp", "move", "blur", "decimate", "expand", "blend", "pair", "equalize", "lummix", "gray", "transfer", "synth"):
+            object.__getattribute__(self, "lib").oracle_set_threads(C.c_int(object.__getattribute__(self, "_n")))
+        return object.__getattribute__(self, name)
 
     @staticmethod
     def _sfx(a):
