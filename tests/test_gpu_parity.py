@@ -427,3 +427,34 @@ def test_random_pairs_against_oracle(st, gpu, oracle, wavefront, seed, monkeypat
     monkeypatch.setenv("STITCH_WAVEFRONT", wavefront)
     done, bad = fz.run(seed, 16)
     assert bad == 0 and done >= 4, (done, bad)  # the other cases ended in the same error code on both sides
+
+
+def test_host_entry_points_reuse_workspaces_and_trim(st, gpu, oracle, monkeypatch):
+    """The host-pointer entry points keep idle workspaces (LRU by canvas and options), device staging and pinned buffers
+    between calls; results must not depend on whether a call found a cached plan, a new one, or ran after stitch_trim(), and
+    large copies (the chunked, threaded path: >= 4 MB) must arrive intact."""
+    rng = np.random.default_rng(3)
+    sizes = [(300, 200), (640, 480), (300, 200), (64, 64), (640, 480)]
+    want = {}
+    for rep in range(2):
+        for (w, h) in sizes:
+            A, B = two_canvases(oracle, w, h, 3, 4, np.uint8)
+            got, _ = st.blend(A, B)
+            if (w, h) not in want:
+                rc, ref, _ = oracle.blend(A, B)
+                assert rc == 0
+                want[(w, h)] = ref
+            assert np.array_equal(got, want[(w, h)]), (rep, w, h)
+        st.capi.lib().stitch_trim()
+    # a pair whose frames and mosaic are well above the threaded-copy threshold, both pixel types, twice
+    fw, fh, cw, ch = 1408, 1024, 2048, 1024
+    for dtype in (np.float32, np.uint8):
+        A, B = oracle.synth(fw, fh, 2, dtype), oracle.synth(fw, fh, 3, dtype)
+        P = [1.0, 0.002, 1e-6, -660.0, -0.001, 1.0, 5e-7, 1.5]
+        rc, ref = oracle.pair(B, P, 0.0, 0.0, A, 0, 0, cw, ch)
+        assert rc == 0
+        for rep in range(2):
+            got, _ = st.pair(B, P, 0.0, 0.0, A, 0, 0, cw, ch)
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (dtype, rep)
+    monkeypatch.setenv("STITCH_PLAN_CACHE", "0")  # read once per process: this only documents the switch
+    st.capi.lib().stitch_trim()
