@@ -458,3 +458,31 @@ def test_host_entry_points_reuse_workspaces_and_trim(st, gpu, oracle, monkeypatc
             assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (dtype, rep)
     monkeypatch.setenv("STITCH_PLAN_CACHE", "0")  # read once per process: this only documents the switch
     st.capi.lib().stitch_trim()
+
+
+def test_host_entry_points_from_two_threads(st, gpu, oracle):
+    """Two host threads in the blend at once (different canvas sizes, one of them above the threaded-copy threshold): the
+    workspace LRU hands every call its own plan, the staging copier serialises, every result equals the oracle's."""
+    import threading
+    jobs = []
+    for (w, h, fa) in [(640, 480, 3), (1600, 1200, 5)]:
+        A, B = two_canvases(oracle, w, h, fa, fa + 1, np.uint8)
+        rc, ref, _ = oracle.blend(A, B)
+        assert rc == 0
+        jobs.append((A, B, ref))
+    errs = []
+
+    def work(job):
+        A, B, ref = job
+        try:
+            for _ in range(3):
+                got, _ = st.blend(A, B)
+                if not np.array_equal(got, ref):
+                    errs.append("mismatch %s" % (A.shape,))
+        except Exception as e:
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not errs, errs
