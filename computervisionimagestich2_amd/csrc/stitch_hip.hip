@@ -616,40 +616,49 @@ int dev_project(const PX* d_src, int w, int h, float fov_deg, PX* d_dst, void* s
     if (rc) return rc;
     if (!d_src || !d_dst || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "project: null buffer or bad size %dx%d", w, h);
     const ProjParams pp = proj_params(w, h, fov_deg);
-    // portrait / square frames: source rows tiled into LDS (k_project_lds) when the largest source box of a tile fits the
-    // budget; everything else (landscape frames, widths that are not a multiple of 4, STITCH_PROJECT1=1): k_project
+    // source rows tiled into LDS (k_project_lds; k_project_lds_t for landscape frames, where the axes swap roles) when the
+    // largest source box of a tile fits the budget; otherwise (widths that are not a multiple of 4, STITCH_PROJECT1=1): k_project
     constexpr int TW = sizeof(PX) == 1 ? 256 : 64, TH = PJ_TH, CPX = PJ_CHUNK / (int)sizeof(PX);
     size_t lds = 0;
-    bool tiled = !pp.flag && (w % 4) == 0 && (unsigned long long)w * h * 3 * sizeof(PX) < 0xfffffff0ULL &&
-                 (reinterpret_cast<uintptr_t>(d_src) % 4) == 0 && !std::getenv("STITCH_PROJECT1");
+    // (float landscape frames stay with k_project: there a wavefront's taps of a row already share their cache lines -- the
+    // source row depends on the output row alone -- and it runs at 0.52 of the roofline, 0.073 ms at 4096 x 3072 against 0.092
+    // through LDS; unsigned char: 0.063 -> 0.050)
+    bool tiled = (w % 4) == 0 && (unsigned long long)w * h * 3 * sizeof(PX) < 0xfffffff0ULL && (reinterpret_cast<uintptr_t>(d_src) % 4) == 0 &&
+                 !(pp.flag && sizeof(PX) == 4) && !std::getenv("STITCH_PROJECT1");
     if (tiled) {
         // the box of a tile, as the kernel derives it, over the tiles that can have the largest one (those farthest from the
-        // axis and from the middle row: the four corner tiles), plus a margin of two rows and two chunks
-        auto col_k = [&](int x) {
-            const float dst_x = (float)(x - w / 2);
-            const double rd = (double)pp.r, dx = (double)dst_x;
-            return (float)(rd / std::sqrt(rd * rd + dx * dx));
+        // axis and from the middle: the four corner tiles), plus a margin of two rows and two chunks.  `along` = the axis k
+        // depends on (columns for portrait frames, rows for landscape ones), `across` the other.
+        const int n_al = pp.flag ? h : w, n_ac = pp.flag ? w : h;
+        auto k_of = [&](int i) {
+            const float d = (float)(i - n_al / 2);
+            const double rd = (double)pp.r, dd = (double)d;
+            return (float)(rd / std::sqrt(rd * rd + dd * dd));
         };
-        auto col_u = [&](int x) { return (float)(x - w / 2) / col_k(x) + (float)(w / 2); };
-        auto row_v = [&](int y, float k) { return (float)(y - h / 2) / k + (float)(h / 2); };
-        const int ntx = (w + TW - 1) / TW, nty = (h + TH - 1) / TH;
-        for (int by : {0, nty - 1})
-            for (int bx : {0, ntx - 1}) {
-                const int xa = bx * TW, ya = by * TH, xb = std::min(xa + TW, w) - 1, yb = std::min(ya + TH, h) - 1;
-                const int xmid = w / 2, xnear = xa <= xmid && xmid <= xb ? xmid : (std::abs(xa - xmid) < std::abs(xb - xmid) ? xa : xb),
-                          xfar = std::abs(xa - xmid) > std::abs(xb - xmid) ? xa : xb;
-                const float kn = col_k(xnear), kf = col_k(xfar);
-                const float vs[4] = {row_v(ya, kn), row_v(ya, kf), row_v(yb, kn), row_v(yb, kf)};
+        auto u_of = [&](int i) { return (float)(i - n_al / 2) / k_of(i) + (float)(n_al / 2); };
+        auto v_of = [&](int j, float k) { return (float)(j - n_ac / 2) / k + (float)(n_ac / 2); };
+        const int t_al = pp.flag ? TH : TW, t_ac = pp.flag ? TW : TH;  // tile extent along / across
+        const int nt_al = (n_al + t_al - 1) / t_al, nt_ac = (n_ac + t_ac - 1) / t_ac;
+        for (int bc : {0, nt_ac - 1})
+            for (int ba : {0, nt_al - 1}) {
+                const int ia = ba * t_al, ib = std::min(ia + t_al, n_al) - 1, ja = bc * t_ac, jb = std::min(ja + t_ac, n_ac) - 1;
+                const int mid = n_al / 2, inear = ia <= mid && mid <= ib ? mid : (std::abs(ia - mid) < std::abs(ib - mid) ? ia : ib),
+                          ifar = std::abs(ia - mid) > std::abs(ib - mid) ? ia : ib;
+                const float kn = k_of(inear), kf = k_of(ifar);
+                const float vs[4] = {v_of(ja, kn), v_of(ja, kf), v_of(jb, kn), v_of(jb, kf)};
                 const float vmin = std::min(std::min(vs[0], vs[1]), std::min(vs[2], vs[3])), vmax = std::max(std::max(vs[0], vs[1]), std::max(vs[2], vs[3]));
-                const long rows = (long)std::ceil(vmax) - (long)std::floor(vmin) + 1 + 2;
-                const long cols = ((long)std::ceil(col_u(xb)) - (long)std::floor(col_u(xa)) + 1 + 2 * CPX + CPX - 1) / CPX * CPX;
+                const long n_across = (long)std::ceil(vmax) - (long)std::floor(vmin) + 1, n_along = (long)std::ceil(u_of(ib)) - (long)std::floor(u_of(ia)) + 1;
+                const long rows = (pp.flag ? n_along : n_across) + 2;
+                const long cols = ((pp.flag ? n_across : n_along) + 2 * CPX + CPX - 1) / CPX * CPX;
                 lds = std::max(lds, (size_t)3 * rows * cols * sizeof(PX));
             }
         tiled = lds <= 60 * 1024;
     }
-    if (tiled)
-        k_project_lds<PX, TW, TH><<<dim3((w + TW - 1) / TW, (h + TH - 1) / TH), 256, lds, as_stream(stream)>>>(d_src, d_dst, w, h, pp.r, d_gray,
-                                                                                                              d_gray_f32, (int)lds);
+    const dim3 tgrid((w + TW - 1) / TW, (h + TH - 1) / TH);
+    if (tiled && !pp.flag)
+        k_project_lds<PX, TW, TH><<<tgrid, 256, lds, as_stream(stream)>>>(d_src, d_dst, w, h, pp.r, d_gray, d_gray_f32, (int)lds);
+    else if (tiled)
+        k_project_lds_t<PX, TW, TH><<<tgrid, 256, lds, as_stream(stream)>>>(d_src, d_dst, w, h, pp.r, d_gray, d_gray_f32, (int)lds);
     else
         k_project<PX><<<grid_xy(w, h), 256, 0, as_stream(stream)>>>(d_src, d_dst, w, h, pp.flag, pp.width, pp.height, pp.r, d_gray,
                                                                     d_gray_f32);

@@ -602,6 +602,99 @@ __global__ __launch_bounds__(256) void k_project_lds(const PX* __restrict__ src,
     }
 }
 
+// Landscape frames (the reference's `flag == 1` branch, Projection.cpp:24-26,30-49: the roles of the axes swap): k and the
+// source ROW u depend on the output row alone, the source column v = (x - w/2)/k(y) + w/2 on both.  Same tiling; the per-row
+// terms of a tile's TH rows are evaluated by TH work-items and shared through LDS, the tile's source box is bounded by its
+// first and last row (u grows with y) and, for the columns, by its rows nearest to / farthest from the axis.
+template <typename PX, int TW, int TH>
+__global__ __launch_bounds__(256) void k_project_lds_t(const PX* __restrict__ src, PX* __restrict__ dst, int w, int h, float r,
+                                                       uint8_t* __restrict__ gray, float* __restrict__ gray_f32, int lds_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pj_smem[];
+    __shared__ ProjCol corner[4], rowc[TH];
+    constexpr int CPX = PJ_CHUNK / (int)sizeof(PX);
+    constexpr int RPT = TH / (256 / TW);
+    const int xa = blockIdx.x * TW, ya = blockIdx.y * TH;
+    const int xb = min(xa + TW, w) - 1, yb = min(ya + TH, h) - 1;
+    if (threadIdx.x < 4) {
+        const int ymid = h / 2, ynear = ya <= ymid && ymid <= yb ? ymid : (abs(ya - ymid) < abs(yb - ymid) ? ya : yb),
+                  yfar = abs(ya - ymid) > abs(yb - ymid) ? ya : yb;
+        const int ys = threadIdx.x == 0 ? ya : threadIdx.x == 1 ? yb : threadIdx.x == 2 ? ynear : yfar;
+        corner[threadIdx.x] = proj_col(ys, h, r);  // the "width" of this branch is the image height
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + TH) rowc[threadIdx.x - 64] = proj_col(min(ya + (int)threadIdx.x - 64, yb), h, r);
+    __syncthreads();
+    int r0 = (int)floorf(corner[0].u), r1 = (int)ceilf(corner[1].u);  // u grows with y
+    r0 = max(r0, 0);
+    r1 = min(r1, h - 1);
+    const float kn = corner[2].k, kf = corner[3].k;
+    const float v00 = proj_v(xa, w, kn), v01 = proj_v(xa, w, kf), v10 = proj_v(xb, w, kn), v11 = proj_v(xb, w, kf);
+    int c0 = (int)floorf(fminf(fminf(v00, v01), fminf(v10, v11))), c1 = (int)ceilf(fmaxf(fmaxf(v00, v01), fmaxf(v10, v11)));
+    c0 = max(c0, 0);
+    c1 = min(c1, w - 1);
+    const int c0a = c0 / CPX * CPX;
+    const int ncol = ((c1 - c0a + 1) + CPX - 1) / CPX * CPX;
+    const int nrow = max(r1 - r0 + 1, 0);
+    const size_t pl = (size_t)w * h;
+    const bool fits = c1 >= c0 && (size_t)3 * nrow * ncol * sizeof(PX) <= (size_t)lds_bytes;
+    PX* tile = reinterpret_cast<PX*>(pj_smem);
+    if (fits) {
+        const __amdgpu_buffer_rsrc_t rs = plane_rsrc(src, 3 * pl);
+        const int cpr = ncol / CPX, lc = threadIdx.x & 31, lr = threadIdx.x >> 5;
+        for (int c = 0; c < 3; ++c)
+            for (int rr = lr; rr < nrow; rr += 8)
+                for (int cc = lc; cc < cpr; cc += 32) {
+                    const unsigned off = (unsigned)((c * pl + (size_t)(r0 + rr) * w + c0a + cc * CPX) * sizeof(PX));
+                    *reinterpret_cast<u4*>(pj_smem + ((size_t)(c * nrow + rr) * ncol + cc * CPX) * sizeof(PX)) =
+                        __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int x = xa + tx;
+    if (x > xb) return;
+    for (int q = 0; q < RPT; ++q) {
+        const int y = ya + ty * RPT + q;
+        if (y > yb) break;
+        const ProjCol rc = rowc[y - ya];
+        const float u = rc.u, v = proj_v(x, w, rc.k);
+        const bool in = u >= 0 && u < (float)h && v >= 0 && v < (float)w;  // width = h, height = w in this branch
+        PX o[3] = {PX(0), PX(0), PX(0)};
+        if (in) {  // bilinear3(src, w, h, x = v, y = u)
+            const int xf = (int)floorf(v), yf = (int)floorf(u);
+            const float cx = ceilf(v), cy = ceilf(u);
+            const int xc = cx >= (float)(w - 1) ? (w - 1) : (int)cx;
+            const int yc = cy >= (float)(h - 1) ? (h - 1) : (int)cy;
+            const float a = v - (float)xf, b = u - (float)yf;
+            const float w_ld = (1 - a) * (1 - b), w_rd = a * (1 - b), w_rt = a * b, w_lt = (1 - a) * b;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float ld, rd_, lt, rt;
+                if (fits) {
+                    const PX* t = tile + (size_t)(c * nrow + (yf - r0)) * ncol + (xf - c0a);
+                    const PX* t2 = t + (size_t)(yc - yf) * ncol;
+                    ld = (float)t[0], rd_ = (float)t[xc - xf], lt = (float)t2[0], rt = (float)t2[xc - xf];
+                } else {
+                    const PX* pc = src + c * pl;
+                    ld = (float)pc[(size_t)yf * w + xf], rd_ = (float)pc[(size_t)yf * w + xc];
+                    lt = (float)pc[(size_t)yc * w + xf], rt = (float)pc[(size_t)yc * w + xc];
+                }
+                o[c] = px_store<PX>(w_ld * ld + w_rd * rd_ + w_rt * rt + w_lt * lt);
+            }
+        }
+        const size_t off = (size_t)y * w + x;
+        dst[off] = o[0];
+        dst[off + pl] = o[1];
+        dst[off + 2 * pl] = o[2];
+        if constexpr (sizeof(PX) == 1) {
+            if (gray || gray_f32) {
+                const uint8_t gv = gray_ref((uint8_t)o[0], (uint8_t)o[1], (uint8_t)o[2]);
+                if (gray) gray[off] = gv;
+                if (gray_f32) gray_f32[off] = (float)gv;
+            }
+        }
+    }
+}
+
 // The level-0 planes of one pair as a FUNCTION of the inputs -- exactly the values k_compose stores (planes 0..2 the
 // warped frame, 3..5 the moved mosaic, 0 where the reference leaves its zeroed canvas untouched).  The consumers of
 // level 0 (seam scan, causal x sweep, level-0 collapse) evaluate it in place when the plan runs "source-fused", so the

@@ -30,13 +30,14 @@ def two_canvases(oracle, w, h, fa, fb, dtype, a_left=True):
     return A, B
 
 
-@pytest.mark.parametrize("w,h", [(384, 512), (1210, 907), (257, 129), (128, 300), (64, 64), (5, 3), (2, 2), (1, 7), (1000, 1000)])
+@pytest.mark.parametrize("w,h", [(384, 512), (1210, 907), (257, 129), (128, 300), (64, 64), (5, 3), (2, 2), (1, 7), (1000, 1000), (1212, 907),
+                                 (2048, 1024), (36, 20)])
 def test_project_u8(st, gpu, oracle, w, h):
     src = oracle.synth(w, h, 3, np.uint8)
     assert np.array_equal(st.project(src), oracle.project(src))
 
 
-@pytest.mark.parametrize("w,h", [(384, 512), (640, 360), (33, 67), (1000, 1000), (128, 300), (4, 4), (1028, 2050)])
+@pytest.mark.parametrize("w,h", [(384, 512), (640, 360), (33, 67), (1000, 1000), (128, 300), (4, 4), (1028, 2050), (2052, 1026)])
 def test_project_f32(st, gpu, oracle, w, h):
     src = oracle.synth(w, h, 5, np.float32)
     got, ref = st.project(src), oracle.project(src)
@@ -156,14 +157,16 @@ def test_blend_errors(st, gpu, oracle):
 def test_project_column_strip_kernel_equals_pixel_kernel(st, gpu, oracle, monkeypatch):
     """k_project4 (four columns per work-item, per-column constants hoisted) against k_project (STITCH_PROJECT1=1) and the
     oracle, fused gray outputs included, on a frame whose rows are not a multiple of the strip height."""
-    src = oracle.synth(1236, 1019, 9, np.uint8)
-    a = st.capi.project_gray(src)
-    monkeypatch.setenv("STITCH_PROJECT1", "1")
-    b = st.capi.project_gray(src)
-    ref = oracle.project(src)
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
-    assert np.array_equal(a[0], ref)
+    for (w, h) in [(1236, 1019), (1236, 1243)]:  # landscape (the axes swap roles) and portrait
+        src = oracle.synth(w, h, 9, np.uint8)
+        monkeypatch.delenv("STITCH_PROJECT1", raising=False)
+        a = st.capi.project_gray(src)
+        monkeypatch.setenv("STITCH_PROJECT1", "1")
+        b = st.capi.project_gray(src)
+        ref = oracle.project(src)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a[0], ref)
 
 
 @pytest.mark.parametrize("w,h", [(1081, 527), (300, 200), (64, 64), (7, 5), (2048, 1024)])
