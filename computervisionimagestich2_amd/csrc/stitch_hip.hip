@@ -618,7 +618,7 @@ int dev_project(const PX* d_src, int w, int h, float fov_deg, PX* d_dst, void* s
     const ProjParams pp = proj_params(w, h, fov_deg);
     // source rows tiled into LDS (k_project_lds; k_project_lds_t for landscape frames, where the axes swap roles) when the
     // largest source box of a tile fits the budget; otherwise (widths that are not a multiple of 4, STITCH_PROJECT1=1): k_project
-    constexpr int TW = sizeof(PX) == 1 ? 256 : 64, TH = PJ_TH, CPX = PJ_CHUNK / (int)sizeof(PX);
+    constexpr int TW = sizeof(PX) == 1 ? PJ_TW_U8 : PJ_TW_F32, TH = sizeof(PX) == 1 ? PJ_TH_U8 : PJ_TH_F32, CPX = PJ_CHUNK / (int)sizeof(PX);
     size_t lds = 0;
     // (float landscape frames stay with k_project: there a wavefront's taps of a row already share their cache lines -- the
     // source row depends on the output row alone -- and it runs at 0.52 of the roofline, 0.073 ms at 4096 x 3072 against 0.092

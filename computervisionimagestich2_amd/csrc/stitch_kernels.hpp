@@ -502,7 +502,21 @@ __device__ __forceinline__ ProjCol proj_col(int x, int w, float r) {  // Project
     return c;
 }
 __device__ __forceinline__ float proj_v(int y, int h, float k) { return (float)(y - h / 2) / k + (float)(h / 2); }
-constexpr int PJ_CHUNK = 16, PJ_TH = 16;  // bytes per staging access; tile rows
+constexpr int PJ_CHUNK = 16;  // bytes per staging access
+// output tile per workgroup: columns x rows, per pixel type (256 work-items: TH / (256 / TW) rows per work-item)
+#ifndef STITCH_PJ_TW_U8
+#define STITCH_PJ_TW_U8 256
+#endif
+#ifndef STITCH_PJ_TH_U8
+#define STITCH_PJ_TH_U8 16
+#endif
+#ifndef STITCH_PJ_TW_F32
+#define STITCH_PJ_TW_F32 64
+#endif
+#ifndef STITCH_PJ_TH_F32
+#define STITCH_PJ_TH_F32 16
+#endif
+constexpr int PJ_TW_U8 = STITCH_PJ_TW_U8, PJ_TH_U8 = STITCH_PJ_TH_U8, PJ_TW_F32 = STITCH_PJ_TW_F32, PJ_TH_F32 = STITCH_PJ_TH_F32;
 template <typename PX, int TW, int TH>
 __global__ __launch_bounds__(256) void k_project_lds(const PX* __restrict__ src, PX* __restrict__ dst, int w, int h, float r,
                                                      uint8_t* __restrict__ gray, float* __restrict__ gray_f32, int lds_bytes) {
