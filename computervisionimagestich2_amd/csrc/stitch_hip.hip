@@ -227,6 +227,11 @@ struct stitch_plan {
     int wf_max_wgs = 2304;  // persistent workgroups of the fused sweep (STITCH_XBYF_WGS)
     unsigned wf_spin_limit = 1u << 20;  // polls before a hand-off wait gives up (STITCH_XBYF_SPIN_LIMIT)
     int wf_early_read = 1;  // STITCH_XBYF_EARLY=0: poll for the hand-off only when it is needed
+    // The causal x sweep of a wavefront level keeps only its state in front of every tile and the fused sweep re-runs it
+    // tile by tile (k_vv_x_fwd<.., CKPT>, k_vv_xbyf MODE 1/2): the x-swept level is neither written nor read back.
+    // STITCH_RECOMPUTE=0 keeps the two-pass form.
+    int recompute = 0;  // 0 off, 1 every wavefront level, 2 the wavefront levels >= 1 only
+    double* ckpt = nullptr;  // [3][tiles of level 0][lines of level 0]
     unsigned long long* wf_dbg = nullptr;  // STITCH_WAVEFRONT_STAMP=1: [wf_max_wgs][8] segment cycle sums (diagnostics)
     // pinned copy of the plan's sticky count of timed-out hand-off waits, refreshed at the end of every call.  The device
     // word only grows (no launch sequence clears it), so the last copy covers every earlier queued call as well.
@@ -323,12 +328,18 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
         }
         if (wavefront) {
             const int nb = (int)((lines + TS - 1) / TS);
+            const bool rcmp = (p->recompute == 1 || (p->recompute == 2 && l >= 1)) && !(p->wf_dbg && l == 0);
             {
                 StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
-                if (src && l == 0)
-                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi);
+                if (src && l == 0) {
+                    if (rcmp)
+                        k_vv_x_fwd<PX, true, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, p->ckpt);
+                    else
+                        k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, nullptr);
+                } else if (rcmp)
+                    k_vv_x_fwd<PX, false, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{}, p->ckpt);
                 else
-                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{});
+                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{}, nullptr);
             }
             Wavefront wf{};
             wf.yg = p->wf_yg;
@@ -353,11 +364,22 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             {
                 StageTimer t(p, s, STITCH_K_VV_XBYF, l);
                 const int wg = (int)std::min<long>(ntiles, p->wf_max_wgs);  // at most 9 workgroups per CU by LDS
+                Recompute rcv{};
+                if (rcmp) {
+                    rcv.in = a.g;
+                    rcv.ckpt = p->ckpt;
+                    rcv.seam = p->d_seam;
+                    if (src && l == 0) rcv.zi = zi;
+                }
                 if (p->wf_dbg && l == 0) {  // diagnostic build: per-segment cycle sums of the level-0 launch
                     wf.dbg = p->wf_dbg;
-                    k_vv_xbyf<true><<<wg, 64, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf);
-                } else
-                    k_vv_xbyf<false><<<wg, 64, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf);
+                    k_vv_xbyf<true><<<wg, 64, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf, rcv, NoPairArgs{});
+                } else if (rcmp && src && l == 0)
+                    k_vv_xbyf<false, PX, 2><<<wg, 64, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf, rcv, pa);
+                else if (rcmp)
+                    k_vv_xbyf<false, float, 1><<<wg, 64, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf, rcv, NoPairArgs{});
+                else
+                    k_vv_xbyf<false><<<wg, 64, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf, rcv, NoPairArgs{});
             }
             StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
             dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
@@ -372,9 +394,9 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
                     if (src && l == 0)
-                    k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi);
-                else
-                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{});
+                        k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, nullptr);
+                    else
+                        k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{}, nullptr);
                 }
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
@@ -1295,6 +1317,9 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     const size_t wfc_off = wf_levels ? take(sizeof(unsigned) * (WF_CTRL_WORDS + WF_STICKY_WORDS)) : 0;
     const size_t zi_off = take((size_t)B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS));
     const size_t zt_off = wf_levels ? take((size_t)7 * B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS)) : 0;
+    int recompute = 2;  // level 0 re-run from the frames measured slower, the plane levels a little faster
+    if (const char* e = std::getenv("STITCH_RECOMPUTE")) recompute = wf_levels > 0 ? std::max(0, std::min(2, atoi(e))) : 0;
+    const size_t ck_off = recompute ? take(sizeof(double) * 3 * NC0 * 7 * B * (size_t)(v0.h + 64)) : 0;
     // x-sweep state [4][lines] followed by the y state the wavefront kernel leaves [4][planes][pitch]
     const size_t state_n = 4 * 7 * B * (size_t)(v0.h + 64) + 4 * 7 * B * (size_t)std::max(v0.h + 64, v0.pitch);
     const size_t st_off = take(sizeof(double) * state_n);
@@ -1329,6 +1354,8 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         p->wf_ctrl = reinterpret_cast<unsigned*>(base + wfc_off);
         p->zt = reinterpret_cast<uint8_t*>(base + zt_off);
         p->zi = reinterpret_cast<uint8_t*>(base + zi_off);
+        p->recompute = recompute;
+        if (recompute) p->ckpt = reinterpret_cast<double*>(base + ck_off);
         if (const char* ew = std::getenv("STITCH_XBYF_WGS")) p->wf_max_wgs = std::max(1, atoi(ew));
         if (const char* es = std::getenv("STITCH_XBYF_SPIN_LIMIT")) p->wf_spin_limit = (unsigned)std::max(0, atoi(es));
         // diagnostic build: one record per persistent workgroup, sized from the workgroup count actually used

@@ -377,7 +377,22 @@ __device__ __forceinline__ bool map_to_src(const MapP& m, float fx, float fy, in
 
 // The degenerate bilinear call of the warp (ImageProcess.cpp:602): a = b = 0, so the value is
 // ((1*1)*ld + (0*1)*rd + (0*0)*rt + (1*0)*lt) = ld*1 + rd*0 + rt*0 + lt*0 with all four taps = ld.
-__device__ __forceinline__ float warp_tap(float ld) { return 1.f * ld + 0.f * ld + 0.f * ld + 0.f * ld; }
+// For every float that expression equals 0*ld + ld rounded once: a finite ld gives 1*ld = ld and 0*ld = a zero of ld's sign,
+// and ld plus zeros of its own sign is ld (-0 included); an infinite or NaN ld gives NaN either way.  One v_fma_f32 instead
+// of seven operations -- the causal x sweep and the collapse of a source-fused level 0 evaluate it for every sample, and the
+// sweep is bound by instruction issue.
+__device__ __forceinline__ float warp_tap(float ld) { return __builtin_fmaf(0.f, ld, ld); }
+// px_store<PX>(warp_tap(t)) as a float, t a sample of a PX frame: a byte value comes through both steps unchanged
+template <typename PX>
+__device__ __forceinline__ float warped_px(float t);
+template <>
+__device__ __forceinline__ float warped_px<float>(float t) {
+    return warp_tap(t);
+}
+template <>
+__device__ __forceinline__ float warped_px<uint8_t>(float t) {
+    return t;
+}
 
 // ---- W2 / W3 stand-alone (read-modify-write canvases of the C++ seam) ---------------------------------------
 template <typename PX>
@@ -739,7 +754,7 @@ struct PairSrc {
         so = (size_t)my * mw + mx;
         return true;
     }
-    __device__ __forceinline__ float frame_val(size_t so, int c) const { return (float)px_store<PX>(warp_tap((float)frame[so + c * fpl])); }
+    __device__ __forceinline__ float frame_val(size_t so, int c) const { return warped_px<PX>((float)frame[so + c * fpl]); }
     __device__ __forceinline__ float mosaic_val(size_t so, int c) const { return (float)mosaic[so + c * mpl]; }
     // plane q (0..5) at canvas pixel (x, y), 0 <= x < cw
     __device__ __forceinline__ float plane(int q, int x, int y) const {
@@ -799,7 +814,10 @@ __device__ __forceinline__ unsigned mosaic_row(const XShift& m, int y) {
 }
 template <typename PX>
 __device__ __forceinline__ unsigned mosaic_offset(unsigned row, unsigned col) {
-    return (row == 0xffffffffu || col == 0xffffffffu) ? off_outside<PX>() : row + col;
+    // saturating add: an "outside" part (all ones) drags the sum to all ones; two valid parts never reach it (planes stay below
+    // 0xfffffff0 bytes).  Masked down to the access size, all ones IS off_outside<PX>().  Two operations instead of five per
+    // sample of the sweep's mosaic planes.
+    return __builtin_elementwise_add_sat(row, col) & (0u - (unsigned)sizeof(PX));
 }
 
 // Sparse canvases.  A stitched canvas is mostly empty for either image (the reference blurs and decimates the zeros
@@ -855,7 +873,7 @@ __global__ __launch_bounds__(256) void k_compose(PairArgs<PX> pa, float* __restr
         if (map_to_src(pa.map[pr], (float)x + pa.offx[pr], (float)y + pa.offy[pr], fw, fh, nx, ny)) {
             const size_t spl = (size_t)fw * fh, so = (size_t)ny * fw + nx;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) a[c] = (float)px_store<PX>(warp_tap((float)frame[so + c * spl]));
+            for (int c = 0; c < 3; ++c) a[c] = warped_px<PX>((float)frame[so + c * spl]);
         }
         const long long mx = (long long)x + pa.ox[pr], my = (long long)y + pa.oy[pr];
         if (mx >= 0 && mx < mw && my >= 0 && my < mh) {
@@ -1080,7 +1098,7 @@ __device__ __forceinline__ void mosaic_indices(const XShift& ms, int c0, int lan
 template <typename PX>
 __device__ __forceinline__ float src_px(__amdgpu_buffer_rsrc_t rs, bool warped, unsigned byte_off) {
     const float v = buf_px<PX>(rs, byte_off);
-    return warped ? (float)px_store<PX>(warp_tap(v)) : v;
+    return warped ? warped_px<PX>(v) : v;
 }
 template <typename PX>
 __device__ __forceinline__ void src_gather(__amdgpu_buffer_rsrc_t rs, const f4 nidx[16], f4 pre[16]) {  // raw bits
@@ -1103,7 +1121,7 @@ __device__ __forceinline__ void src_finish(bool warped, f4 pre[16]) {  // raw bi
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float t = raw_to_px<PX>(v[j]);
-            v[j] = warped ? (float)px_store<PX>(warp_tap(t)) : t;
+            v[j] = warped ? warped_px<PX>(t) : t;
         }
         pre[i] = v;
     }
@@ -1113,10 +1131,14 @@ __device__ __forceinline__ void src_finish(bool warped, f4 pre[16]) {  // raw bi
 // allocated with 64 spare rows so that a partial last block may touch rows >= lines without leaving them.
 // Level 0 of a source-fused plan (use_src; needs mk.enabled, i.e. a level height that is a multiple of 64): the input
 // tile is not read from `in` but evaluated from the pair's frames (PairSrc), so S1 never materialises.
-template <typename PX, bool SRC>
+// CKPT (a level whose anticausal sweep re-runs the causal one tile by tile, k_vv_xbyf MODE 1/2): the swept samples are not
+// written at all; what is kept is the recurrence state in front of every tile (ckpt[3][tiles][lines], doubles), from which
+// the consumer reproduces the tile's samples exactly -- 24 bytes per 64 samples instead of 256 written and read back.
+template <typename PX, bool SRC, bool CKPT = false>
 __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, float* __restrict__ out, int w, int pitch,
                                                   long lines, VVK k, double* __restrict__ state, MaskL0 mk,
-                                                  typename CollapseSrc<PX, SRC>::type pa, ZeroTiles zt, ZeroTiles zi) {
+                                                  typename CollapseSrc<PX, SRC>::type pa, ZeroTiles zt, ZeroTiles zi,
+                                                  double* __restrict__ ckpt) {
     __shared__ __attribute__((aligned(16))) float tile[TS * TP];
     const int lane = threadIdx.x;
     long blk = blockIdx.x;
@@ -1159,15 +1181,14 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
     // plane (frame channels) or computed (the mosaic is a pure shift).
     f4 nidx[SRC ? 16 : 1];
     // index tile t of this block's band: from the index plane, or all "outside" when k_src_index left the tile's flag set
+    // frame channels: tile t of this band lies outside the frame altogether (k_src_index's flag): its samples are +0
+    auto tile_outside = [&](int t) -> bool {
+        if constexpr (SRC) return gen_frame && zi.flags && zi.flags[zi.index(src_pr, src_y0 >> 6, t)];
+        return false;
+    };
     auto index_tile = [&](int t) {
-        if constexpr (SRC) {
-            if (zi.flags && zi.flags[zi.index(src_pr, src_y0 >> 6, t)]) {
-                const float o = __uint_as_float(off_outside<PX>());
-#pragma unroll
-                for (int i = 0; i < 16; ++i) nidx[i] = f4{o, o, o, o};
-            } else
-                tile_load(idx_rows, pitch, t * TS, lane, nidx);
-        }
+        if constexpr (SRC)
+            if (!tile_outside(t)) tile_load(idx_rows, pitch, t * TS, lane, nidx);  // an outside tile is not gathered at all
     };
     auto gen_tile = [&](int c0, f4 pre[16]) {
         f4 v;
@@ -1193,7 +1214,10 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
         if (gen_mask)                                                          \
             gen_tile((T) * TS, pre);                                           \
         else if constexpr (SRC) {                                              \
-            src_gather<PX>(rs, nidx, pre);                                     \
+            if (tile_outside(T)) {                                             \
+                _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) pre[i_] = f4{0.f, 0.f, 0.f, 0.f}; \
+            } else                                                             \
+                src_gather<PX>(rs, nidx, pre);                                 \
             if ((T) + 1 < ntiles) {                                            \
                 if (gen_frame)                                                 \
                     index_tile((T) + 1);                                       \
@@ -1211,6 +1235,15 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
     }
     STITCH_X_FETCH(0);
     for (int t = 0; t < ntiles; ++t) {
+        // Zeros in under a zero state: every product and sum of the recurrence is +0 again, the state stays as it is and the
+        // tile would be recorded as all +0 -- recorded at once.  (In a stitch step the frame's canvas is empty left of the
+        // frame: a third of the frame channels' tiles in config 2.)
+        if (!CKPT && zt.flags && tile_outside(t) &&
+            (t == 0 || __ballot((__double_as_longlong(v1) | __double_as_longlong(v2) | __double_as_longlong(v3)) != 0) == 0)) {
+            if (t + 1 < ntiles) STITCH_X_FETCH(t + 1);
+            if (lane == 0) zt.flags[zt.index(line0 / zt.h, (int)((line0 % zt.h) / TS), t)] = 1;
+            continue;
+        }
         if constexpr (SRC)
             if (!gen_mask) src_finish<PX>(gen_frame, pre);
         tile_to_lds(tile, lane, pre);
@@ -1219,6 +1252,12 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
         float* row = tile + lane * TP;
         const int jmax = min(TS, w - t * TS);
         if (t == 0) v1 = v2 = v3 = (double)row[0] / k.sumsq;  // CImg.h:34909
+        if (CKPT && t > 0 && live) {
+            double* c = ckpt + (size_t)(3 * t) * lines + line;
+            c[0] = v1;
+            c[lines] = v2;
+            c[2 * lines] = v3;
+        }
         const int jfull = jmax & ~15;
         unsigned nz = 0;  // OR of the bit patterns this lane stores: 0 <=> every sample is +0.0f
         for (int jb = 0; jb < jfull; jb += 16) {
@@ -1237,16 +1276,19 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
                 v2 = v1;
                 v1 = v0;
             }
+            if (!CKPT) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<f4*>(row + jb + 4 * q) = *reinterpret_cast<const f4*>(xs + 4 * q);
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f4*>(row + jb + 4 * q) = *reinterpret_cast<const f4*>(xs + 4 * q);
+            }
         }
         for (int j = jfull; j < jmax; ++j) {  // ragged tail of the last tile, straight from LDS
             double v0 = (double)row[j];
             v0 += v1 * k.f1;
             v0 += v2 * k.f2;
             v0 += v3 * k.f3;
-            row[j] = (float)v0;
-            nz |= __float_as_uint(row[j]);
+            const float f = (float)v0;
+            if (!CKPT) row[j] = f;
+            nz |= __float_as_uint(f);
             v3 = v2;
             v2 = v1;
             v1 = v0;
@@ -1257,7 +1299,7 @@ __global__ __launch_bounds__(64) void k_vv_x_fwd(const float* __restrict__ in, f
             if (lane == 0) zt.flags[zt.index(line0 / zt.h, (int)((line0 % zt.h) / TS), t)] = zero ? 1 : 0;
             if (zero) continue;
         }
-        tile_store(ob, pitch, t * TS, lane, tile);
+        if (!CKPT) tile_store(ob, pitch, t * TS, lane, tile);
     }
     if (live) {
         state[line] = v1;
@@ -1812,10 +1854,22 @@ __device__ __forceinline__ bool granules_consume(const u64* base, int lane, unsi
     }
 }
 
-template <bool STAMP>
+//
+// MODE 0: the samples the causal x sweep left are read from `data` and swept in place.  MODE 1 / 2: the causal x sweep ran
+// as k_vv_x_fwd<.., CKPT> and kept only its state in front of every tile; this kernel fetches the level's INPUT tile (MODE 1:
+// the planes `in`; MODE 2, source-fused level 0: the pair's frames through the index plane, as k_vv_x_fwd<PX, true> does),
+// re-runs the 64 causal steps from the checkpoint in LDS -- the same operations on the same operands, so the same bits --
+// and carries on as MODE 0.  The level's x-swept samples never travel to HBM and back.
+struct Recompute {
+    const float* in;       // MODE 1: level input planes; MODE 2: the plan's level-0 planes (slot 0 of a pair = its index plane)
+    const double* ckpt;    // [3][tiles][lines]
+    const SeamDev* seam;   // implicit level-0 mask: band 0 of a mask plane generates the step
+    ZeroTiles zi;          // MODE 2: index tiles that lie outside the frame
+};
+template <bool STAMP, typename PX = float, int MODE = 0>
 __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w, int h, int pitch, VVK k,
                                                  const double* __restrict__ state_x, long lines, double* __restrict__ state_y,
-                                                 Wavefront wf) {
+                                                 Wavefront wf, Recompute rc, typename CollapseSrc<PX, MODE == 2>::type pa) {
     __shared__ __attribute__((aligned(16))) float tile[TS * TP];
     const int lane = threadIdx.x;
     const unsigned nbands = (unsigned)wf.NP * wf.NR;
@@ -1858,18 +1912,72 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             triggs(k, iplus, v1, v2, v3, first);
         }
         f4 pre[16];
-        // tile C of this band into `pre`: from HBM, or zeros when the causal x sweep recorded it as all +0
+        // MODE 1/2: where this band's input comes from (all wave-uniform)
+        const int src_q = p % 7, src_pr = p / 7;
+        const bool gen_mask = MODE != 0 && pass_row;  // band 0 of an implicit mask plane: the step itself
+        const bool gen_frame = MODE == 2 && src_q < 3, gen_mosaic = MODE == 2 && src_q >= 3 && src_q < 6;
+        const float* in_base = MODE == 1 ? rc.in + ((size_t)p * h + r0) * pitch : nullptr;
+        const float* idx_rows = MODE == 2 ? rc.in + ((size_t)src_pr * 7 * h + r0) * pitch : nullptr;  // rows r0.. of the pair's index plane
+        const __amdgpu_buffer_rsrc_t rs = x_rsrc<PX>(pa, src_pr, src_q);
+        const XShift ms = x_shift<PX>(pa, src_pr);
+        SeamDev sd{};
+        if (gen_mask) sd = rc.seam[src_pr];
+        // checkpoint of tile C (the causal state in front of its first sample); tile 0 starts from the boundary value instead
+        const long cline = (long)p * h + r0 + lane;
+        double n1 = 0, n2 = 0, n3 = 0;
+        auto fetch_ckpt = [&](int C) {
+            if (MODE != 0 && C > 0 && lane < nrows) {
+                const double* c = rc.ckpt + (size_t)(3 * C) * lines + cline;
+                n1 = c[0];
+                n2 = c[lines];
+                n3 = c[2 * lines];
+            }
+        };
+        // Tile C of this band into `pre`: from HBM, or zeros when the causal x sweep recorded it as all +0.  MODE 2 fetches in
+        // two steps through the SAME registers: fetch_tile puts the tile's element indices into `pre` (index plane, frame
+        // channels), gather_tile -- issued one sweep later -- replaces them by the samples (a second register tile for the
+        // indices would halve the wavefronts per SIMD).
         auto fetch_tile = [&](int C) {  // true: the tile is all +0
-            if (wf.zt.flags && wf.zt.flags[wf.zt.index(p, R, C)]) {
+            const bool zero = wf.zt.flags && wf.zt.flags[wf.zt.index(p, R, C)];
+            if (zero) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) pre[i] = f4{0.f, 0.f, 0.f, 0.f};
-                return true;
+            } else if (MODE == 0)
+                tile_load(base, pitch, C * TS, lane, pre);
+            else if (gen_mask) {
+                f4 v;
+                const int c = C * TS + ((lane & 15) << 2);
+                v.x = mask_step(sd, c);
+                v.y = mask_step(sd, c + 1);
+                v.z = mask_step(sd, c + 2);
+                v.w = mask_step(sd, c + 3);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pre[i] = v;
+            } else if (MODE == 1)
+                tile_load(in_base, pitch, C * TS, lane, pre);
+            else if (gen_frame) {
+                if (rc.zi.flags && rc.zi.flags[rc.zi.index(src_pr, R, C)]) {
+                    const float o = __uint_as_float(off_outside<PX>());
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) pre[i] = f4{o, o, o, o};
+                } else
+                    tile_load(idx_rows, pitch, C * TS, lane, pre);
             }
-            tile_load(base, pitch, C * TS, lane, pre);
-            return false;
+            if (MODE != 0 && !zero) fetch_ckpt(C);
+            return zero;
+        };
+        auto gather_tile = [&](int C, bool zero) {
+            if constexpr (MODE == 2) {
+                if (zero || gen_mask) return;
+                if (gen_mosaic) mosaic_indices<PX>(ms, C * TS, lane, r0, w, pre);
+                src_gather<PX>(rs, pre, pre);
+            }
         };
         bool next_zero = false, spec = true;
-        if (!const_rows) next_zero = fetch_tile(wf.NC - 1);
+        if (!const_rows) {
+            next_zero = fetch_tile(wf.NC - 1);
+            gather_tile(wf.NC - 1, next_zero);
+        }
         for (int C = wf.NC - 1; C >= 0; --C) {
             const int c0 = C * TS, ncols = min(TS, w - c0);
             const bool tile_zero = next_zero;  // the tile now going to LDS holds +0 only
@@ -1879,12 +1987,50 @@ __global__ __launch_bounds__(64) void k_vv_xbyf(float* __restrict__ data, int w,
             // by the poll) and probed again every fourth tile
             const bool early_on = R > 0 && wf.early_read && (spec || (C & 3) == 0);
             if (early_on) granules_issue(slot, lane, early);  // ahead of the prefetch below (in-order return)
+            double f1 = n1, f2 = n2, f3 = n3;  // this tile's checkpoint (MODE 1/2)
             if (!const_rows) {
+                if constexpr (MODE == 2)
+                    if (!tile_zero && !gen_mask) src_finish<PX>(gen_frame, pre);
                 tile_to_lds(tile, lane, pre);
                 if (C > 0) next_zero = fetch_tile(C - 1);  // next tile of the band, in flight during both sweeps
             }
             __syncthreads();
             stamp(1);  // tile fetch
+            // ---- MODE 1/2: the causal x sweep of this tile again, lane = row r0+lane (k_vv_x_fwd's loop) -------------
+            if (MODE != 0 && !const_rows && !tile_zero) {
+                float* row = tile + lane * TP;
+                if (C == 0) f1 = f2 = f3 = (double)row[0] / k.sumsq;  // CImg.h:34909
+                const int jfull = ncols & ~15;
+                for (int jb = 0; jb < jfull; jb += 16) {
+                    float xs[16];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f4*>(xs + 4 * qq) = *reinterpret_cast<const f4*>(row + jb + 4 * qq);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        double v0 = (double)xs[u];
+                        v0 += f1 * k.f1;
+                        v0 += f2 * k.f2;
+                        v0 += f3 * k.f3;
+                        xs[u] = (float)v0;
+                        f3 = f2;
+                        f2 = f1;
+                        f1 = v0;
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<f4*>(row + jb + 4 * qq) = *reinterpret_cast<const f4*>(xs + 4 * qq);
+                }
+                for (int j = jfull; j < ncols; ++j) {
+                    double v0 = (double)row[j];
+                    v0 += f1 * k.f1;
+                    v0 += f2 * k.f2;
+                    v0 += f3 * k.f3;
+                    row[j] = (float)v0;
+                    f3 = f2;
+                    f2 = f1;
+                    f1 = v0;
+                }
+            }
+            if (!const_rows && C > 0) gather_tile(C - 1, next_zero);  // MODE 2: the indices have arrived during the causal sweep
             // ---- anticausal x sweep, lane = row r0+lane ---------------------------------------------------------
             // Zeros in, zero state: every product and sum of the recurrence is +0 again (x*sum = +0, and +0 plus a zero of
             // either sign is +0), so the sweep would rewrite the zeros it found and leave the state as it is: skipped.
@@ -2381,7 +2527,7 @@ struct SrcRow4 {
     __device__ __forceinline__ void finish(float a[4], float b[4]) const {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            a[j] = (float)px_store<PX>(warp_tap(raw_to_px<PX>(a[j])));
+            a[j] = warped_px<PX>(raw_to_px<PX>(a[j]));
             b[j] = raw_to_px<PX>(b[j]);
         }
     }
