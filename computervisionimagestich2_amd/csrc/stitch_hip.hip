@@ -1317,7 +1317,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     const size_t wfc_off = wf_levels ? take(sizeof(unsigned) * (WF_CTRL_WORDS + WF_STICKY_WORDS)) : 0;
     const size_t zi_off = take((size_t)B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS));
     const size_t zt_off = wf_levels ? take((size_t)7 * B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS)) : 0;
-    int recompute = 2;  // level 0 re-run from the frames measured slower, the plane levels a little faster
+    int recompute = 0;  // opt-in: level 0 re-run from the frames measured 3 % slower, the plane levels within noise
     if (const char* e = std::getenv("STITCH_RECOMPUTE")) recompute = wf_levels > 0 ? std::max(0, std::min(2, atoi(e))) : 0;
     const size_t ck_off = recompute ? take(sizeof(double) * 3 * NC0 * 7 * B * (size_t)(v0.h + 64)) : 0;
     // x-sweep state [4][lines] followed by the y state the wavefront kernel leaves [4][planes][pitch]

@@ -156,6 +156,10 @@ int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
  *   STITCH_XBYF_SPIN_LIMIT=<n> polls before a hand-off wait of the fused sweep gives up (default 2^20; 0 forces the
  *                             bail-out path: tests of the sticky time-out report)
  *   STITCH_XBYF_EARLY=0       fused sweep: poll for the hand-off only when it is needed (default: read it ahead of the prefetch)
+ *   STITCH_RECOMPUTE=<0|1|2>  fused levels: 0 (default) = the causal x sweep writes its samples and the fused sweep reads
+ *                             them back; 1 = it keeps only its state in front of every 64-sample tile and the fused sweep
+ *                             re-runs it from there (level 0 straight from the frames); 2 = that form at the fused levels >= 1
+ *                             only.  Fewer bytes, more dependent arithmetic per tile: measured slower (1) / equal (2)
  * The stitch_dev_pairs_* launch sequence contains no host synchronisation and no per-launch state in kernel
  * arguments: it may be captured into a HIP graph and replayed on new contents of the same buffers. */
 

@@ -28,6 +28,8 @@ GROUP = {"k_compose": "compose", "k_src_index": "compose", "k_seam": "seam", "k_
          "k_collapse<unsigned char, true>": "collapse_l0", "k_collapse4<float, false>": "collapse", "k_collapse4<float, true>": "collapse_l0",
          "k_collapse4<unsigned char, true>": "collapse_l0", "k_blend_top": "collapse_top", "k_vv_xbyf<false>": "vv_xbyf",
          "k_vv_xbyf<true>": "vv_xbyf"}
+# template arguments added later (CKPT of the causal sweep, pixel type and MODE of the fused sweep) do not change the group
+GROUP_PREFIX = {"k_vv_x_fwd<": "vv_x_fwd", "k_vv_xbyf<": "vv_xbyf"}
 LAUNCH_GROUPS = {"compose": 1, "seam": 1, "mask": 1, "vv_x_fwd": 11, "vv_x_bwd": 9, "vv_y_fwd": 9, "vv_y_bwd": 11, "decimate": 0,
                  "collapse_top": 1, "collapse": 10, "collapse_l0": 1, "vv_xbyf": 2}  # config 2 with two fused-sweep levels
 
@@ -63,7 +65,7 @@ fetch, fmax = counter("FETCH_SIZE")
 write, wmax = counter("WRITE_SIZE")
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    g = GROUP.get(k)
+    g = GROUP.get(k) or next((v for pre, v in GROUP_PREFIX.items() if k.startswith(pre)), None)
     if g is None:
         continue
     e = out.setdefault(g, {"fetch_kib_per_step": 0.0, "write_kib_per_step": 0.0, "kernels": []})
