@@ -1641,15 +1641,18 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
     unsigned long long zm[4] = {0, 0, 0, 0};
     const bool zt_on = zt.flags != nullptr;
     if (zt_on) {
-        const uint8_t* ztcol = zt.flags + zt.index(blockIdx.y, 0, (col_live ? x : 0) >> 6);
+        // a wavefront's 128 columns are two tiles (lanes 0..31 / 32..63): lane i fetches the flag of band g*64+i of either tile
+        // (the bands of a tile column are contiguous bytes) and a ballot turns 64 flags into the mask
+        const int tA = blockIdx.x * 2;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g * 64 < zt.NR) {  // wave-uniform
-                unsigned char fb[64];
-#pragma unroll
-                for (int i = 0; i < 64; ++i) fb[i] = g * 64 + i < zt.NR ? ztcol[g * 64 + i] : 0;
-#pragma unroll
-                for (int i = 0; i < 64; ++i) zm[g] |= (unsigned long long)(fb[i] != 0) << i;
+                const int band = g * 64 + lane;
+                const bool inb = band < zt.NR;
+                const unsigned char fa = inb ? zt.flags[zt.index(blockIdx.y, band, tA)] : 0;
+                const unsigned char fb = inb && tA + 1 < zt.NC ? zt.flags[zt.index(blockIdx.y, band, tA + 1)] : 0;
+                const unsigned long long mA = __ballot(fa != 0), mB = __ballot(fb != 0);
+                zm[g] = lane < 32 ? mA : mB;
             }
         }
     }
@@ -1690,11 +1693,13 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
     const bool dst_live = tx < w2;
     float Xp1 = 0.f, Xp2 = 0.f;  // x-decimated rows y+1 and y+2 (previous two rows in processing order)
 
-    for (int j0 = 0; j0 <= nchunks; j0 += YST) {
+    // The two roles run separate loops (same trip count, one barrier per chunk each): in one loop body the producer's 64
+    // registers of prefetched rows would stay allocated across the consumer's code.
+    if (wave == 0) {
+        for (int j0 = 0; j0 <= nchunks; j0 += YST) {
 #pragma unroll
-        for (int st = 0; st < YST; ++st) {
-            const int j = j0 + st;
-            if (wave == 0) {
+            for (int st = 0; st < YST; ++st) {
+                const int j = j0 + st;
                 const bool z = chunk_zero(j + YST - 1);
 #pragma unroll
                 for (int u = 0; u < YCH; ++u) buf[(st + YST - 1) % YST][u] = ld((j + YST - 1) * YCH + u, z);
@@ -1707,33 +1712,63 @@ __global__ __launch_bounds__(128) void k_vv_y_bwd_dec(const float* __restrict__ 
                         *reinterpret_cast<f2*>(&ring[st & 1][u][2 * lane]) = o;
                     }
                 }
-            } else if (j >= 1 && j - 1 < nchunks) {
-                const int jc = j - 1;
+                __syncthreads();
+            }
+        }
+    } else {
+        for (int j0 = 0; j0 <= nchunks; j0 += YST) {
 #pragma unroll
-                for (int u = 0; u < YCH; ++u) {
-                    const int rc = jc * YCH + u;
-                    if (rc < h) {
-                        const int y = h - 1 - rc;
+            for (int st = 0; st < YST; ++st) {
+                const int j = j0 + st;
+                if (j >= 1 && j - 1 < nchunks) {
+                    // The rows of a chunk are independent until the y step, and a row is one dependent chain (LDS read, two
+                    // multiply-adds, an IEEE divide): all YCH chains are laid side by side, free of branches, so that they overlap --
+                    // row after row the consumer was the slower wavefront of the two (264 cycles per row against the producer's
+                    // 173).  Rows past the image (last chunk) are computed from whatever the ring holds and never stored.
+                    const int rc0 = (j - 1) * YCH;
+                    float E[YCH + 2];  // x-decimated rows: E[0], E[1] = the two rows before this chunk, E[2 + u] = row rc0 + u
+                    E[0] = Xp2;
+                    E[1] = Xp1;
+#pragma unroll
+                    for (int u = 0; u < YCH; ++u) {
                         const f2 v = *reinterpret_cast<const f2*>(&ring[(st + 1) & 1][u][2 * lane]);
                         float X = 0.f;
                         X += v.x * fsx;
                         X += v.y * fsx;
                         X /= fw;
-                        if ((y & 1) == 0 && (y >> 1) < h2) {  // row y = 2t completes output row t
-                            const int t = y >> 1;
-                            float a2 = 0.f;
-                            a2 += X * (h_odd ? (float)(unsigned)(h2 - t) : fsy);
-                            a2 += Xp1 * fsy;
-                            if (h_odd) a2 += Xp2 * (float)(unsigned)(t + 1);
-                            a2 /= fh;
-                            if (dst_live) dcol[(size_t)t * dpitch] = a2;
-                        }
-                        Xp2 = Xp1;
-                        Xp1 = X;
+                        E[2 + u] = X;
+                        if (u == YCH / 2 - 1) __builtin_amdgcn_sched_barrier(0);  // two groups of four: eight divides side by side need 140 VGPRs
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // row y = 2t completes output row t; y = h-1-rc0-u and rc0 is a multiple of YCH (even): for an even height the
+                    // odd u, for an odd height the even u
+                    if (h_odd) {
+#pragma unroll
+                        for (int u = 0; u < YCH; u += 2) {
+                            const int y = h - 1 - rc0 - u, t = y >> 1;
+                            float a2 = 0.f;
+                            a2 += E[2 + u] * (float)(unsigned)(h2 - t);
+                            a2 += E[1 + u] * fsy;
+                            a2 += E[u] * (float)(unsigned)(t + 1);
+                            a2 /= fh;
+                            if (y >= 0 && t < h2 && dst_live) dcol[(size_t)t * dpitch] = a2;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 1; u < YCH; u += 2) {
+                            const int y = h - 1 - rc0 - u, t = y >> 1;
+                            float a2 = 0.f;
+                            a2 += E[2 + u] * fsy;
+                            a2 += E[1 + u] * fsy;
+                            a2 /= fh;
+                            if (y >= 0 && t < h2 && dst_live) dcol[(size_t)t * dpitch] = a2;
+                        }
+                    }
+                    Xp2 = E[YCH];
+                    Xp1 = E[YCH + 1];
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
     if (state_out && wave == 0 && col_live) y2_store(state_out, (size_t)gridDim.y * pitch, ystate_index(blockIdx.y, pitch, x), s);
