@@ -408,7 +408,10 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
                 {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
-                    k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
+                    if ((long)g.x * g.y < 1536 && !std::getenv("STITCH_Y2"))  // fewer than 1.5 wavefronts per SIMD: one column per work-item
+                        k_vv_y_fwd1<<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
+                    else
+                        k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
                 }
                 StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
                 if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass

@@ -1430,16 +1430,16 @@ __device__ __forceinline__ Taps make_taps(int t, int n_src, int n_dst) {
 // (YCH*(YST-1) = 24 rows in flight per wavefront while one chunk computes).  In place.
 // grid = (ceil(pitch/128), planes); pitch is a multiple of 64, a last half-empty block is masked off.
 constexpr int YCH = 8, YST = 4, YCOLS = 2 * WAVE;
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Calls f(y, value) for rows y_begin, y_begin +/- 1, ... (count rows), loading each row's value long before.
-template <bool DOWN, typename F>
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <bool DOWN, typename V = f2, typename F>
 __device__ __forceinline__ void stream_rows(const float* __restrict__ p, int pitch, int y_begin, int count, F&& f) {
-    f2 buf[YST][YCH];
+    V buf[YST][YCH];
     // row index is clamped instead of predicated: the tail re-reads the last row, the loop body stays branch-free
     auto ld = [&](int i) {
         const int ic = i < count ? i : count - 1;
-        return *reinterpret_cast<const f2*>(p + (size_t)(DOWN ? y_begin + ic : y_begin - ic) * pitch);
+        return *reinterpret_cast<const V*>(p + (size_t)(DOWN ? y_begin + ic : y_begin - ic) * pitch);
     };
 #pragma unroll
     for (int s = 0; s < YST - 1; ++s)
@@ -1554,6 +1554,43 @@ __global__ __launch_bounds__(64) void k_vv_y_fwd(float* __restrict__ data, int h
     state[2 * n + i + 1] = s.b3;
     state[3 * n + i] = (double)last.x;
     state[3 * n + i + 1] = (double)last.y;
+}
+
+// The same sweep with ONE column per work-item, for launches that leave SIMDs idle (a single pair: 7 planes x 6144 columns are
+// 336 wavefronts of two columns on 1024 SIMDs).  A double-precision operation occupies its SIMD for 8 cycles per wavefront and
+// hands its result on after about 24: two interleaved chains are bound by issue (16 operations = 128 cycles per row), one
+// chain by latency (4 dependent operations = 96 cycles) -- and there are twice as many wavefronts to spread.
+__global__ __launch_bounds__(64) void k_vv_y_fwd1(float* __restrict__ data, int h, int pitch, size_t ps, VVK k,
+                                                   double* __restrict__ state, MaskL0 mk, const double* __restrict__ resume) {
+    const int x = blockIdx.x * WAVE + threadIdx.x;  // pitch is a multiple of 64
+    float* p = data + blockIdx.y * ps + x;
+    const bool side = mk.enabled && (blockIdx.y % 7 == 6);
+    const float* src = side ? mk.side + (size_t)(blockIdx.y / 7) * pitch + x : p;
+    const int spitch = side ? 0 : pitch;
+    const float last = src[(size_t)(h - 1) * spitch];
+    const float x0 = src[0];
+    double v1, v2, v3;
+    v1 = v2 = v3 = (double)x0 / k.sumsq;
+    const size_t n = (size_t)gridDim.y * pitch, i = ystate_index(blockIdx.y, pitch, x);
+    if (resume) {
+        v1 = resume[i];
+        v2 = resume[n + i];
+        v3 = resume[2 * n + i];
+    }
+    stream_rows<true, float>(src, spitch, 0, h, [&](int y, float xv) {
+        double v0 = (double)xv;
+        v0 += v1 * k.f1;
+        v0 += v2 * k.f2;
+        v0 += v3 * k.f3;
+        v3 = v2;
+        v2 = v1;
+        v1 = v0;
+        p[(size_t)y * pitch] = (float)v0;
+    });
+    state[i] = v1;
+    state[n + i] = v2;
+    state[2 * n + i] = v3;
+    state[3 * n + i] = (double)last;
 }
 
 __device__ __forceinline__ void y2_triggs(const VVK& k, const double* __restrict__ state, size_t n, size_t i, Y2& s, f2& first) {

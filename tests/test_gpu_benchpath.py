@@ -72,6 +72,8 @@ def test_fused_sweep_many_bands_per_workgroup(st, gpu, oracle, monkeypatch, dtyp
     monkeypatch.setenv("STITCH_XBYF_WGS", str(wgs))
     if recompute is not None:
         monkeypatch.setenv("STITCH_RECOMPUTE", str(recompute))
+    if wgs == 7:
+        monkeypatch.setenv("STITCH_Y2", "1")  # the coarser levels' causal y sweep with two columns per work-item (big launches' form)
     B = 3
     plan = capi.Plan(cw, ch, max_pairs=B)
     assert plan.fused_sweep_levels == 2
