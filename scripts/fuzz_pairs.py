@@ -20,13 +20,33 @@ def run(seed, N, verbose=True):
     return done, bad
 
 
+SWITCHES = {"STITCH_WAVEFRONT": [None, "0", "1", "2"], "STITCH_RECOMPUTE": [None, "1", "2"], "STITCH_Y2": [None, "1"],
+            "STITCH_COLLAPSE4": [None, "0"], "STITCH_NO_ZERO_TILES": [None, "1"], "STITCH_NO_SRC_FUSE": [None, "1"]}
+
+
 def _case(case, rng, O, capi, torch, dev, bad, done, verbose):
     if True:
-        ch = 64 * int(rng.integers(2, 9))
-        cw = 2 * int(rng.integers(max(33, ch // 4 + 1), ch))  # even, within a factor two of the height (else the pyramid degenerates)
+        general = os.environ.get("FUZZ_GENERAL") == "1"
+        if general:
+            # any size and parity, every tuning switch drawn per case (none of them may change a bit)
+            ch = int(rng.integers(65, 640))
+            cw = int(rng.integers(max(66, ch // 2 + 1), 2 * ch))
+            for k, vals in SWITCHES.items():
+                v = vals[int(rng.integers(0, len(vals)))]
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        else:
+            ch = 64 * int(rng.integers(2, 9))
+            cw = 2 * int(rng.integers(max(33, ch // 4 + 1), ch))  # even, within a factor two of the height (else the pyramid degenerates)
         B = int(rng.integers(1, 4))
         dtype = np.float32 if rng.random() < 0.6 else np.uint8
-        plan = capi.Plan(cw, ch, max_pairs=B)
+        opts = dict(sigma=2.0, blur_kind=0, level_rule=0, seam_rule=0)
+        if general and rng.random() < 0.4:  # the ex6 variant's rules and other blur widths (0.3: below both filters' cut-off)
+            opts = dict(sigma=float(rng.choice([0.3, 0.8, 1.5, 2.0, 3.5])), blur_kind=int(rng.integers(0, 2)), level_rule=int(rng.integers(0, 2)),
+                        seam_rule=int(rng.integers(0, 2)))
+        plan = capi.Plan(cw, ch, opts=opts, max_pairs=B)
         items, refs = [], []
         for i in range(B):
             fw, fh = int(rng.integers(40, cw)), int(rng.integers(40, ch + 60))
@@ -36,7 +56,7 @@ def _case(case, rng, O, capi, torch, dev, bad, done, verbose):
                  rng.normal() * 1e-5, rng.normal() * 15]
             offx, offy = (0.0, 0.0) if rng.random() < 0.5 else (float(np.float32(rng.normal() * 3)), float(np.float32(rng.normal() * 3)))
             F, M = O.synth(fw, fh, 2 * case + 1, dtype), O.synth(mw, mh, 2 * case, dtype)
-            rc, ref = O.pair(F, P, offx, offy, M, ox, oy, cw, ch)
+            rc, ref = O.pair(F, P, offx, offy, M, ox, oy, cw, ch, opts)
             items.append((torch.from_numpy(F).to(dev), P, offx, offy, torch.from_numpy(M).to(dev), ox, oy,
                           torch.empty((3, ch, cw), dtype=torch.uint8 if dtype == np.uint8 else torch.float32, device=dev)))
             refs.append((rc, ref))
@@ -55,13 +75,15 @@ def _case(case, rng, O, capi, torch, dev, bad, done, verbose):
                 done += 1
                 if not same:
                     d = outs[i].cpu().numpy().astype(np.float64) - ref.astype(np.float64)
-                    print("PIXEL MISMATCH", case, i, (cw, ch, B, dtype.__name__), np.abs(d).max(), (d != 0).sum()); bad += 1
+                    print("PIXEL MISMATCH", case, i, (cw, ch, B, dtype.__name__), np.abs(d).max(), (d != 0).sum(),
+                          {k: os.environ.get(k) for k in SWITCHES}, opts); bad += 1
         plan.close()
         return bad, done
 
 
 if __name__ == "__main__":
-    os.environ.setdefault("STITCH_WAVEFRONT", "2")
+    if os.environ.get("FUZZ_GENERAL") != "1":
+        os.environ.setdefault("STITCH_WAVEFRONT", "2")
     done, bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 7, int(sys.argv[2]) if len(sys.argv) > 2 else 30)
-    print(f"fuzz: {done} pairs compared bit for bit, {bad} mismatches, fused levels forced = {os.environ['STITCH_WAVEFRONT']}")
+    print(f"fuzz: {done} pairs compared bit for bit, {bad} mismatches, fused levels forced = {os.environ.get('STITCH_WAVEFRONT')}")
     sys.exit(1 if bad else 0)

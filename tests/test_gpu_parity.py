@@ -432,6 +432,22 @@ def test_random_pairs_against_oracle(st, gpu, oracle, wavefront, seed, monkeypat
     assert bad == 0 and done >= 4, (done, bad)  # the other cases ended in the same error code on both sides
 
 
+def test_random_pairs_any_size_every_switch(st, gpu, oracle, monkeypatch):
+    """The general mode of the same generator: canvases of any size and parity, every tuning switch of include/stitch.h drawn
+    per case (fused levels, re-run form of the causal sweep, column width of the y sweep, collapse form, zero-tile flags,
+    source fusion) and, for four cases in ten, the ex6 variant's rules, both blurs and other sigmas.  A switch may never
+    change a bit.  (3 000 cases of this run were compared once per round with scripts/fuzz_pairs.py directly.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_pairs", os.path.join(os.path.dirname(HERE), "scripts", "fuzz_pairs.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    monkeypatch.setenv("FUZZ_GENERAL", "1")
+    for k in fz.SWITCHES:  # the generator sets and clears them itself: restore whatever was there afterwards
+        monkeypatch.setenv(k, "0")
+    done, bad = fz.run(5, 80)
+    assert bad == 0 and done >= 40, (done, bad)
+
+
 def test_host_entry_points_reuse_workspaces_and_trim(st, gpu, oracle, monkeypatch):
     """The host-pointer entry points keep idle workspaces (LRU by canvas and options), device staging and pinned buffers
     between calls; results must not depend on whether a call found a cached plan, a new one, or ran after stitch_trim(), and
