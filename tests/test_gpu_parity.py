@@ -448,6 +448,27 @@ def test_random_pairs_any_size_every_switch(st, gpu, oracle, monkeypatch):
     assert bad == 0 and done >= 40, (done, bad)
 
 
+def test_bad_arguments_are_refused(st, gpu):
+    """Null pointers, non-positive sizes, a null map, a too-small output buffer, a bad rank: 58 calls over every family of
+    entry points (scripts/argprobe.py holds the table) -- each must return STITCH_ERR_ARG with a message and touch nothing.
+    (The reference has no error paths at all here: SURVEY.md 5.)"""
+    import ctypes as C
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("argprobe_table", os.path.join(os.path.dirname(HERE), "scripts", "argprobe.py"))
+    src = open(spec.origin).read().split("if len(sys.argv) > 1:")[0]  # the table only, not the driver below it
+    ns = {"__file__": spec.origin, "__name__": "argprobe_table"}
+    exec(compile(src, spec.origin, "exec"), ns)
+    L = st.capi.lib()
+    buf = (C.c_uint8 * (1 << 20))()
+    table = ns["calls"](L, buf)
+    assert len(table) >= 58
+    for name, call in table.items():
+        rc = call()
+        assert rc == st.capi.ERR_ARG, (name, rc)
+        assert L.stitch_last_error(), name
+    assert not any(buf), "a refused call wrote into a buffer"
+
+
 def test_host_entry_points_reuse_workspaces_and_trim(st, gpu, oracle, monkeypatch):
     """The host-pointer entry points keep idle workspaces (LRU by canvas and options), device staging and pinned buffers
     between calls; results must not depend on whether a call found a cached plan, a new one, or ran after stitch_trim(), and
