@@ -2792,13 +2792,53 @@ __global__ void k_emit_top(const float* __restrict__ e_all, int w, int h, int pi
 
 // ---- E1-E3 / M1: equalisation and luminance mix --------------------------------------------------------------
 __device__ __forceinline__ float clamp256(float v) { return v > 0 ? (v < 256 ? v : 255.f) : 0.f; }
-// equalization.cpp:78-80 / ImageProcess.cpp:242-244: double expressions, float store, float clamp
-__device__ __forceinline__ void rgb_to_ycc(float r, float g, float b, float& Y, float& Cb, float& Cr) {
-    Y = clamp256((float)(0.299 * (double)r + 0.857 * (double)g + 0.114 * (double)b));  // 0.857 sic
-    Cb = clamp256((float)(128.0 - 0.168736 * (double)r - 0.331264 * (double)g + 0.5 * (double)b));
-    Cr = clamp256((float)(128.0 + 0.5 * (double)r - 0.418688 * (double)g - 0.081312 * (double)b));
+// ---- the colour transforms on BYTE inputs, in integers -------------------------------------------------------------------
+// equalization.cpp:78-80 / ImageProcess.cpp:242-244 evaluate   Y  = 0.299 R + 0.857 G + 0.114 B   (0.857 sic)
+//                                                              Cb = 128 - 0.168736 R - 0.331264 G + 0.5 B
+//                                                              Cr = 128 + 0.5 R - 0.418688 G - 0.081312 B
+// in double, store to float and clamp in float.  R, G, B are bytes, so the exact values are t / 1000 and t / 10^6 with integer
+// t (ycc_terms); the double evaluation is within 1e-13 of them, and no t / 10^k comes within 7e-9 of a point where the float
+// rounding could go either way -- so   (float)((double)t * 1e-k)   IS the reference's float, and its truncation (the
+// CImg<unsigned char> store of equalization.cpp:83-85) is the integer quotient t / 10^k (Cb and Cr lie in 0.5 .. 255.5 and all
+// their t are multiples of 32, never just below an integer).  Likewise the way back from BYTE Y, Cb, Cr (equalization.cpp:93-98):
+// Y + 1.402 (Cr-128) etc. are t / 1000 and t / 10^5, the clamp and the truncation are max(0, min(255, t / 10^k)).
+// tests/test_oracle_golden.py::test_integer_colour_transforms_are_exact checks every one of the 2^24 inputs of either direction
+// against the double / float expressions; the GPU kernels are compared with the oracle on an image that holds every colour.
+// A pixel costs a few integer multiply-adds instead of ~25 double-precision operations (which occupy a SIMD for 8 cycles each).
+struct YccTerms {
+    unsigned ty, tcb, tcr;  // 1000 Y, 10^6 Cb, 10^6 Cr
+};
+__device__ __forceinline__ YccTerms ycc_terms(unsigned r, unsigned g, unsigned b) {
+    YccTerms t;
+    t.ty = 299u * r + 857u * g + 114u * b;
+    t.tcb = 128000000u - 168736u * r - 331264u * g + 500000u * b;  // 0.5e6 .. 255.5e6
+    t.tcr = 128000000u + 500000u * r - 418688u * g - 81312u * b;
+    return t;
 }
-// equalization.cpp:93-98 / ImageProcess.cpp:262-267
+// the float Y, Cb, Cr the reference holds (ImageProcess.cpp:242-244: not truncated there)
+__device__ __forceinline__ void rgb_to_ycc(unsigned r, unsigned g, unsigned b, float& Y, float& Cb, float& Cr) {
+    const YccTerms t = ycc_terms(r, g, b);
+    Y = clamp256((float)((double)t.ty * 0.001));
+    Cb = clamp256((float)((double)t.tcb * 1e-6));
+    Cr = clamp256((float)((double)t.tcr * 1e-6));
+}
+// the bytes equalization.cpp:83-85 stores
+__device__ __forceinline__ void rgb_to_ycc_bins(unsigned r, unsigned g, unsigned b, unsigned& yq, unsigned& cbq, unsigned& crq) {
+    const YccTerms t = ycc_terms(r, g, b);
+    const unsigned q = t.ty / 1000u;
+    yq = q < 255u ? q : 255u;
+    cbq = t.tcb / 1000000u;
+    crq = t.tcr / 1000000u;
+}
+__device__ __forceinline__ unsigned clamp_quot(int t, int d) { return t <= 0 ? 0u : (t >= 256 * d ? 255u : (unsigned)t / (unsigned)d); }
+// equalization.cpp:93-98 on byte Y, Cb, Cr
+__device__ __forceinline__ void ycc_bins_to_rgb(unsigned y, unsigned cb, unsigned cr, unsigned& r, unsigned& g, unsigned& b) {
+    const int Y = (int)y, cbd = (int)cb - 128, crd = (int)cr - 128;
+    r = clamp_quot(1000 * Y + 1402 * crd, 1000);
+    g = clamp_quot(100000 * Y - 34414 * cbd - 71414 * crd, 100000);
+    b = clamp_quot(1000 * Y + 1772 * cbd, 1000);
+}
+// equalization.cpp:93-98 / ImageProcess.cpp:262-267 on float inputs (the luminance mix)
 __device__ __forceinline__ void ycc_to_rgb_u8(float Y, float Cb, float Cr, uint8_t& r, uint8_t& g, uint8_t& b) {
     const float R = (float)((double)Y + 1.402 * ((double)Cr - 128.0));
     const float G = (float)((double)Y - 0.34414 * ((double)Cb - 128.0) - 0.71414 * ((double)Cr - 128.0));
@@ -2840,17 +2880,25 @@ __global__ __launch_bounds__(HIST_WAVES * 64) void k_hist(const uint8_t* __restr
     }
 }
 
-// CDF and LUT (equalization.cpp:110-124): 256 sequential double additions -- kept sequential on one lane so
-// that the running sum is bit-identical; round() is half-away-from-zero.
-__global__ void k_lut(const int32_t* __restrict__ hist, int w, int h, int32_t* __restrict__ lut) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// CDF and LUT (equalization.cpp:110-124): p_i = hist_i / total for all bins side by side (the divisions are independent),
+// then the running sum as 256 sequential double additions on one lane -- its order is the reference's, so the sum is
+// bit-identical -- then lut_i = round(255 cdf_i) side by side again; round() is half-away-from-zero.  (All on one lane this took
+// 20 us -- a sixth of an equalisation of 25 MPix: every iteration waited for a double-precision divide.)
+__global__ __launch_bounds__(256) void k_lut(const int32_t* __restrict__ hist, int w, int h, int32_t* __restrict__ lut) {
+    __shared__ double pc[256];
     const double total = (double)(w * h);
-    double cdf = 0.0;
-    for (int i = 0; i < 256; ++i) {
-        const double p = (double)hist[i] / total;
-        cdf = (i == 0) ? p : cdf + p;
-        lut[i] = (int32_t)round(255.0 * cdf);
+    const int i = threadIdx.x;
+    pc[i] = (double)hist[i] / total;
+    __syncthreads();
+    if (i == 0) {
+        double cdf = pc[0];
+        for (int j = 1; j < 256; ++j) {
+            cdf = cdf + pc[j];
+            pc[j] = cdf;
+        }
     }
+    __syncthreads();
+    lut[i] = (int32_t)round(255.0 * pc[i]);
 }
 
 // apply (equalization.cpp:127-130 + :92-99), in place; FUSE_MIX additionally performs M1 so that the equalised
@@ -2863,22 +2911,21 @@ __global__ __launch_bounds__(256) void k_equalize_apply(uint8_t* __restrict__ im
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float r = (float)img[i], g = (float)img[i + n], b = (float)img[i + 2 * n];
-        float Y, Cb, Cr;
-        rgb_to_ycc(r, g, b, Y, Cb, Cr);
-        const uint8_t yq = (uint8_t)(int)Y, cbq = (uint8_t)(int)Cb, crq = (uint8_t)(int)Cr;  // CImg<uchar> store
-        const uint8_t yeq = (uint8_t)slut[yq];
-        uint8_t er, eg, eb;
-        ycc_to_rgb_u8((float)yeq, (float)cbq, (float)crq, er, eg, eb);
+        const unsigned r = img[i], g = img[i + n], b = img[i + 2 * n];
+        unsigned yq, cbq, crq, er, eg, eb;
+        rgb_to_ycc_bins(r, g, b, yq, cbq, crq);  // CImg<uchar> store
+        ycc_bins_to_rgb((unsigned)slut[yq] & 255u, cbq, crq, er, eg, eb);
+        uint8_t o0 = (uint8_t)er, o1 = (uint8_t)eg, o2 = (uint8_t)eb;
         if (FUSE_MIX) {
-            float Ye, Cbe, Cre;
-            rgb_to_ycc((float)er, (float)eg, (float)eb, Ye, Cbe, Cre);
+            float Y, Cb, Cr, Ye, Cbe, Cre;
+            rgb_to_ycc(r, g, b, Y, Cb, Cr);
+            rgb_to_ycc(er, eg, eb, Ye, Cbe, Cre);
             const float Ym = (float)((double)Y * num / den + (double)Ye / den);  // ImageProcess.cpp:261
-            ycc_to_rgb_u8(Ym, Cb, Cr, er, eg, eb);
+            ycc_to_rgb_u8(Ym, Cb, Cr, o0, o1, o2);
         }
-        img[i] = er;
-        img[i + n] = eg;
-        img[i + 2 * n] = eb;
+        img[i] = o0;
+        img[i + n] = o1;
+        img[i + 2 * n] = o2;
     }
 }
 
@@ -2888,8 +2935,8 @@ __global__ __launch_bounds__(256) void k_lummix(uint8_t* __restrict__ res, const
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float Y, Cb, Cr, Ye, Cbe, Cre;
-        rgb_to_ycc((float)res[i], (float)res[i + n], (float)res[i + 2 * n], Y, Cb, Cr);
-        rgb_to_ycc((float)eq[i], (float)eq[i + n], (float)eq[i + 2 * n], Ye, Cbe, Cre);
+        rgb_to_ycc(res[i], res[i + n], res[i + 2 * n], Y, Cb, Cr);
+        rgb_to_ycc(eq[i], eq[i + n], eq[i + 2 * n], Ye, Cbe, Cre);
         const float Ym = (float)((double)Y * num / den + (double)Ye / den);
         uint8_t r, g, b;
         ycc_to_rgb_u8(Ym, Cb, Cr, r, g, b);
@@ -2942,28 +2989,30 @@ __global__ __launch_bounds__(256) void k_equalize_apply4(uint8_t* __restrict__ i
     unsigned* __restrict__ pb = reinterpret_cast<unsigned*>(img + 2 * n);
     const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float r[4], g[4], b[4];
-        unpack4(pr[i], r);
-        unpack4(pg[i], g);
-        unpack4(pb[i], b);
-        uint8_t er[4], eg[4], eb[4];
+        const unsigned wr = pr[i], wg = pg[i], wb = pb[i];
+        unsigned o_r = 0, o_g = 0, o_b = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float Y, Cb, Cr;
-            rgb_to_ycc(r[j], g[j], b[j], Y, Cb, Cr);
-            const uint8_t yq = (uint8_t)(int)Y, cbq = (uint8_t)(int)Cb, crq = (uint8_t)(int)Cr;  // CImg<uchar> store
-            const uint8_t yeq = (uint8_t)slut[yq];
-            ycc_to_rgb_u8((float)yeq, (float)cbq, (float)crq, er[j], eg[j], eb[j]);
+            const unsigned r = (wr >> (8 * j)) & 255u, g = (wg >> (8 * j)) & 255u, b = (wb >> (8 * j)) & 255u;
+            unsigned yq, cbq, crq, er, eg, eb;
+            rgb_to_ycc_bins(r, g, b, yq, cbq, crq);  // CImg<uchar> store
+            ycc_bins_to_rgb((unsigned)slut[yq] & 255u, cbq, crq, er, eg, eb);
             if (FUSE_MIX) {
-                float Ye, Cbe, Cre;
-                rgb_to_ycc((float)er[j], (float)eg[j], (float)eb[j], Ye, Cbe, Cre);
+                float Y, Cb, Cr, Ye, Cbe, Cre;
+                rgb_to_ycc(r, g, b, Y, Cb, Cr);
+                rgb_to_ycc(er, eg, eb, Ye, Cbe, Cre);
                 const float Ym = (float)((double)Y * num / den + (double)Ye / den);  // ImageProcess.cpp:261
-                ycc_to_rgb_u8(Ym, Cb, Cr, er[j], eg[j], eb[j]);
+                uint8_t m0, m1, m2;
+                ycc_to_rgb_u8(Ym, Cb, Cr, m0, m1, m2);
+                er = m0, eg = m1, eb = m2;
             }
+            o_r |= er << (8 * j);
+            o_g |= eg << (8 * j);
+            o_b |= eb << (8 * j);
         }
-        pr[i] = Px4<uint8_t>::pack(er);
-        pg[i] = Px4<uint8_t>::pack(eg);
-        pb[i] = Px4<uint8_t>::pack(eb);
+        pr[i] = o_r;
+        pg[i] = o_g;
+        pb[i] = o_b;
     }
 }
 

@@ -186,6 +186,30 @@ def test_equalize_lummix_finish(st, gpu, oracle, w, h):
     assert np.array_equal(st.lummix(img, got, 5.0, 6.0), oracle.lummix(img, ref, 5.0, 6.0))
 
 
+def test_equalize_every_colour(st, gpu, oracle):
+    """The equalisation and mix kernels evaluate the colour transforms of byte pixels in integers (stitch_kernels.hpp,
+    ycc_terms): an image that holds each of the 2^24 colours once (plus a copy permuted so that the equalised partner of a
+    pixel varies) must come out of equalise, mix and finish exactly as the oracle's double / float evaluation gives it; 4095
+    columns wide as well, so that the byte kernels (plane size not a multiple of 4) see every colour too."""
+    v = np.arange(256, dtype=np.uint8)
+    R, G, B = np.meshgrid(v, v, v, indexing="ij")
+    img = np.stack([R, G, B]).reshape(3, 4096, 4096).copy()
+    ref, rhist, _ = oracle.equalize(img)
+    got, hist = st.equalize(img)
+    assert np.array_equal(hist, rhist) and np.array_equal(got, ref)
+    other = np.ascontiguousarray(ref[:, ::-1, ::-1])  # every colour mixed with some other equalised colour
+    assert np.array_equal(st.lummix(img, other), oracle.lummix(img, other))
+    assert np.array_equal(st.lummix(img, other, 7.0, 9.0), oracle.lummix(img, other, 7.0, 9.0))
+    fin, _ = st.finish(img)
+    assert np.array_equal(fin, oracle.lummix(img, ref))
+    odd = np.ascontiguousarray(img[:, :, :4095])
+    ref2, rh2, _ = oracle.equalize(odd)
+    got2, h2 = st.equalize(odd)
+    assert np.array_equal(h2, rh2) and np.array_equal(got2, ref2)
+    fin2, _ = st.finish(odd)
+    assert np.array_equal(fin2, oracle.lummix(odd, ref2))
+
+
 def test_blend_random_sizes_sweep(st, gpu, oracle):
     """Random canvas sizes (odd/even at every level -> fused and stand-alone decimation, implicit and materialised
     level-0 mask, both seam branches) for both pixel types, against the oracle."""

@@ -290,6 +290,59 @@ def test_integer_luma_bin_is_exact(oracle):
     assert np.array_equal(hist, np.bincount(integ.ravel(), minlength=256))
 
 
+def test_integer_colour_transforms_are_exact(oracle):
+    """stitch_kernels.hpp evaluates RGB -> YCbCr (equalization.cpp:78-85, ImageProcess.cpp:242-244) and YCbCr -> RGB
+    (equalization.cpp:93-98) of BYTE inputs in integers: t = 299 R + 857 G + 114 B etc. (ycc_terms), the float value as
+    (float)(t * 1e-k), the stored byte as t // 10^k, the way back as max(0, min(255, t // 10^k)).  Checked here for every one of
+    the 2^24 inputs of either direction against the reference's double -> float -> clamp -> truncate expressions (the oracle's
+    own rgb_to_ycbcr / ycbcr_to_rgb_u8 are these expressions; the GPU test test_equalize_every_colour closes the loop)."""
+    def clamp(x):
+        return np.where(x > 0, np.where(x < 256, x, np.float32(255)), np.float32(0)).astype(np.float32)
+
+    def quot(t, d):
+        return np.where(t <= 0, 0, np.minimum(255, t // d))
+
+    v = np.arange(256, dtype=np.int64)
+    mine = np.empty((3, 256, 256, 256), np.uint8)
+    img = np.empty((3, 256, 256, 256), np.uint8)
+    lut = None
+    for pass_ in range(2):  # pass 0: the transforms; pass 1: the oracle's equalisation of every colour through the integer formulas
+        if pass_ == 1:
+            ref, hist, lut = oracle.equalize(img.reshape(3, 4096, 4096))
+            lut = np.asarray(lut, dtype=np.int64) & 255
+        for r0 in range(0, 256, 32):  # slabs of 32 values of the first coordinate: 2 M inputs at a time
+            R, G, B = np.meshgrid(v[r0:r0 + 32], v, v, indexing="ij")
+            ty = 299 * R + 857 * G + 114 * B
+            tcb = 128000000 - 168736 * R - 331264 * G + 500000 * B
+            tcr = 128000000 + 500000 * R - 418688 * G - 81312 * B
+            if pass_ == 1:
+                yeq, cbq, crq = lut[np.minimum(255, ty // 1000)], tcb // 1000000, tcr // 1000000
+                mine[0, r0:r0 + 32] = quot(1000 * yeq + 1402 * (crq - 128), 1000)
+                mine[1, r0:r0 + 32] = quot(100000 * yeq - 34414 * (cbq - 128) - 71414 * (crq - 128), 100000)
+                mine[2, r0:r0 + 32] = quot(1000 * yeq + 1772 * (cbq - 128), 1000)
+                continue
+            img[0, r0:r0 + 32], img[1, r0:r0 + 32], img[2, r0:r0 + 32] = R, G, B
+            Rf, Gf, Bf = R.astype(np.float64), G.astype(np.float64), B.astype(np.float64)
+            y = ((0.299 * Rf + 0.857 * Gf) + 0.114 * Bf).astype(np.float32)
+            cb = (((128.0 - 0.168736 * Rf) - 0.331264 * Gf) + 0.5 * Bf).astype(np.float32)
+            cr = (((128.0 + 0.5 * Rf) - 0.418688 * Gf) - 0.081312 * Bf).astype(np.float32)
+            assert tcb.min() > 0 and tcr.min() > 0 and tcb.max() < 256000000 and tcr.max() < 256000000
+            assert np.array_equal((ty.astype(np.float64) * 0.001).astype(np.float32), y)
+            assert np.array_equal((tcb.astype(np.float64) * 1e-6).astype(np.float32), cb)
+            assert np.array_equal((tcr.astype(np.float64) * 1e-6).astype(np.float32), cr)
+            assert np.array_equal(np.minimum(255, ty // 1000), clamp(y).astype(np.int64))
+            assert np.array_equal(tcb // 1000000, clamp(cb).astype(np.int64))
+            assert np.array_equal(tcr // 1000000, clamp(cr).astype(np.int64))
+            # the same slab read as byte (Y, Cb, Cr) = (R, G, B): the way back
+            r8 = clamp((Rf + 1.402 * (Bf - 128.0)).astype(np.float32)).astype(np.int64)
+            g8 = clamp(((Rf - 0.34414 * (Gf - 128.0)) - 0.71414 * (Bf - 128.0)).astype(np.float32)).astype(np.int64)
+            b8 = clamp((Rf + 1.772 * (Gf - 128.0)).astype(np.float32)).astype(np.int64)
+            assert np.array_equal(quot(1000 * R + 1402 * (B - 128), 1000), r8)
+            assert np.array_equal(quot(100000 * R - 34414 * (G - 128) - 71414 * (B - 128), 100000), g8)
+            assert np.array_equal(quot(1000 * R + 1772 * (G - 128), 1000), b8)
+    assert np.array_equal(mine.reshape(3, 4096, 4096), ref)
+
+
 def test_blend_ex6_goldens(oracle):
     """The src/ex6 variant's whole blend (seam_rule = level_rule = blur_kind = 1): the oracle against the bytes the variant's
     own function produced (golden.json "blend_ex6", tests/golden/add_ex6_goldens.py)."""
