@@ -29,8 +29,9 @@ def _case(case, rng, O, capi, torch, dev, bad, done, verbose):
         general = os.environ.get("FUZZ_GENERAL") == "1"
         if general:
             # any size and parity, every tuning switch drawn per case (none of them may change a bit)
-            ch = int(rng.integers(65, 640))
-            cw = int(rng.integers(max(66, ch // 2 + 1), 2 * ch))
+            big = os.environ.get("FUZZ_BIG") == "1"  # canvases up to 3072 x 2048, batches up to 8: the sizes where the fused sweep is chosen by itself
+            ch = int(rng.integers(65, 2048 if big else 640))
+            cw = int(rng.integers(max(66, ch // 2 + 1), min(2 * ch, 3072) + 1))
             for k, vals in SWITCHES.items():
                 v = vals[int(rng.integers(0, len(vals)))]
                 if v is None:
@@ -40,7 +41,7 @@ def _case(case, rng, O, capi, torch, dev, bad, done, verbose):
         else:
             ch = 64 * int(rng.integers(2, 9))
             cw = 2 * int(rng.integers(max(33, ch // 4 + 1), ch))  # even, within a factor two of the height (else the pyramid degenerates)
-        B = int(rng.integers(1, 4))
+        B = int(rng.integers(1, 9 if os.environ.get("FUZZ_BIG") == "1" else 4))
         dtype = np.float32 if rng.random() < 0.6 else np.uint8
         opts = dict(sigma=2.0, blur_kind=0, level_rule=0, seam_rule=0)
         if general and rng.random() < 0.4:  # the ex6 variant's rules and other blur widths (0.3: below both filters' cut-off)
