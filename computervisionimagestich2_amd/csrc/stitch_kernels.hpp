@@ -520,7 +520,7 @@ __device__ __forceinline__ float proj_v(int y, int h, float k) { return (float)(
 constexpr int PJ_CHUNK = 16;  // bytes per staging access
 // output tile per workgroup: columns x rows, per pixel type (256 work-items: TH / (256 / TW) rows per work-item)
 #ifndef STITCH_PJ_TW_U8
-#define STITCH_PJ_TW_U8 256
+#define STITCH_PJ_TW_U8 128
 #endif
 #ifndef STITCH_PJ_TH_U8
 #define STITCH_PJ_TH_U8 16
@@ -529,9 +529,50 @@ constexpr int PJ_CHUNK = 16;  // bytes per staging access
 #define STITCH_PJ_TW_F32 64
 #endif
 #ifndef STITCH_PJ_TH_F32
-#define STITCH_PJ_TH_F32 16
+#define STITCH_PJ_TH_F32 32
 #endif
 constexpr int PJ_TW_U8 = STITCH_PJ_TW_U8, PJ_TH_U8 = STITCH_PJ_TH_U8, PJ_TW_F32 = STITCH_PJ_TW_F32, PJ_TH_F32 = STITCH_PJ_TH_F32;
+// Staging of a tile's source box (three channels, rows r0 .. r0+nrow-1, columns c0a .. c0a+ncol-1) into LDS with 16-byte
+// loads: 32 lanes across a row's chunks, 8 rows per pass (no division by the run-time chunk count).  All loads of a work-item
+// are issued before the first LDS store -- a loop of load -> store iterations put up to nine HBM round trips of a workgroup
+// one behind the other, which was half of the float kernel's time (0.134 -> 0.067 ms at 4096 x 4096 with the staging ablated).
+// A chunk that is not this lane's reads at an offset beyond the buffer: no traffic, the value is dropped.
+// PJ_MAXP row passes are held in registers (boxes of up to 8 PJ_MAXP rows and 32 chunks per row; larger ones loop): the box of a
+// TH-row tile has about 1.1 TH + 3 rows.
+template <typename PX, int PJ_MAXP>
+__device__ __forceinline__ void pj_stage(const PX* __restrict__ src, size_t pl, int w, int r0, int nrow, int c0a, int ncol, uint8_t* smem) {
+    constexpr int CPX = PJ_CHUNK / (int)sizeof(PX);
+    const __amdgpu_buffer_rsrc_t rs = plane_rsrc(src, 3 * pl);  // a chunk that runs past the last row reads 0
+    const int cpr = ncol / CPX, lc = threadIdx.x & 31, lr = threadIdx.x >> 5;
+    if (cpr <= 32 && nrow <= 8 * PJ_MAXP) {
+        u4 v[3][PJ_MAXP];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int p = 0; p < PJ_MAXP; ++p) {
+                const int rr = lr + 8 * p;
+                const bool mine = rr < nrow && lc < cpr;
+                const unsigned off = mine ? (unsigned)((c * pl + (size_t)(r0 + rr) * w + c0a + lc * CPX) * sizeof(PX)) : 0xfffffff0u;
+                v[c][p] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int p = 0; p < PJ_MAXP; ++p) {
+                const int rr = lr + 8 * p;
+                if (rr < nrow && lc < cpr) *reinterpret_cast<u4*>(smem + ((size_t)(c * nrow + rr) * ncol + lc * CPX) * sizeof(PX)) = v[c][p];
+            }
+        return;
+    }
+    for (int c = 0; c < 3; ++c)
+        for (int rr = lr; rr < nrow; rr += 8)
+            for (int cc = lc; cc < cpr; cc += 32) {
+                const unsigned off = (unsigned)((c * pl + (size_t)(r0 + rr) * w + c0a + cc * CPX) * sizeof(PX));
+                *reinterpret_cast<u4*>(smem + ((size_t)(c * nrow + rr) * ncol + cc * CPX) * sizeof(PX)) =
+                    __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            }
+}
+
 template <typename PX, int TW, int TH>
 __global__ __launch_bounds__(256) void k_project_lds(const PX* __restrict__ src, PX* __restrict__ dst, int w, int h, float r,
                                                      uint8_t* __restrict__ gray, float* __restrict__ gray_f32, int lds_bytes) {
@@ -570,16 +611,7 @@ __global__ __launch_bounds__(256) void k_project_lds(const PX* __restrict__ src,
     const bool fits = c1 >= c0 && (size_t)3 * nrow * ncol * sizeof(PX) <= (size_t)lds_bytes;  // the host sized lds_bytes for every tile
     PX* tile = reinterpret_cast<PX*>(pj_smem);
     if (fits) {
-        const __amdgpu_buffer_rsrc_t rs = plane_rsrc(src, 3 * pl);  // a chunk that runs past the last row reads 0
-        // 32 lanes across a row's chunks, 8 rows per pass (no division by the run-time chunk count)
-        const int cpr = ncol / CPX, lc = threadIdx.x & 31, lr = threadIdx.x >> 5;
-        for (int c = 0; c < 3; ++c)
-            for (int rr = lr; rr < nrow; rr += 8)
-                for (int cc = lc; cc < cpr; cc += 32) {
-                    const unsigned off = (unsigned)((c * pl + (size_t)(r0 + rr) * w + c0a + cc * CPX) * sizeof(PX));
-                    *reinterpret_cast<u4*>(pj_smem + ((size_t)(c * nrow + rr) * ncol + cc * CPX) * sizeof(PX)) =
-                        __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-                }
+        pj_stage<PX, ((TH + TH / 8 + 11) / 8 > 4 ? (TH + TH / 8 + 11) / 8 : 4)>(src, pl, w, r0, nrow, c0a, ncol, pj_smem);
     }
     __syncthreads();
     if (xa + tx > xb) return;
@@ -667,15 +699,7 @@ __global__ __launch_bounds__(256) void k_project_lds_t(const PX* __restrict__ sr
     const bool fits = c1 >= c0 && (size_t)3 * nrow * ncol * sizeof(PX) <= (size_t)lds_bytes;
     PX* tile = reinterpret_cast<PX*>(pj_smem);
     if (fits) {
-        const __amdgpu_buffer_rsrc_t rs = plane_rsrc(src, 3 * pl);
-        const int cpr = ncol / CPX, lc = threadIdx.x & 31, lr = threadIdx.x >> 5;
-        for (int c = 0; c < 3; ++c)
-            for (int rr = lr; rr < nrow; rr += 8)
-                for (int cc = lc; cc < cpr; cc += 32) {
-                    const unsigned off = (unsigned)((c * pl + (size_t)(r0 + rr) * w + c0a + cc * CPX) * sizeof(PX));
-                    *reinterpret_cast<u4*>(pj_smem + ((size_t)(c * nrow + rr) * ncol + cc * CPX) * sizeof(PX)) =
-                        __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-                }
+        pj_stage<PX, ((TH + TH / 8 + 11) / 8 > 4 ? (TH + TH / 8 + 11) / 8 : 4)>(src, pl, w, r0, nrow, c0a, ncol, pj_smem);
     }
     __syncthreads();
     const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
