@@ -2977,6 +2977,7 @@ __global__ __launch_bounds__(256) void k_lummix(uint8_t* __restrict__ res, const
 // that equal bins of different copies fall into different banks): images saturate (the 0.857 coefficient pushes bright
 // pixels to Y = 255) and neighbouring pixels share bins, and LDS atomics on one address serialise.
 constexpr int HIST_COPIES = 8, HIST_PITCH = 257;
+typedef unsigned u4a __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte access at 4-byte alignment
 __device__ __forceinline__ void unpack4(unsigned w, float v[4]) {
     v[0] = (float)(w & 255u), v[1] = (float)((w >> 8) & 255u), v[2] = (float)((w >> 16) & 255u), v[3] = (float)(w >> 24);
 }
@@ -2988,8 +2989,22 @@ __global__ __launch_bounds__(HIST_WAVES * 64) void k_hist4(const uint8_t* __rest
     const unsigned* __restrict__ pr = reinterpret_cast<const unsigned*>(img);
     const unsigned* __restrict__ pg = reinterpret_cast<const unsigned*>(img + n);
     const unsigned* __restrict__ pb = reinterpret_cast<const unsigned*>(img + 2 * n);
-    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const size_t n4 = n / 4, n16 = n4 / 4, stride = (size_t)gridDim.x * blockDim.x;
+    // sixteen pixels per step (dword-aligned 16-byte loads): with 512 workgroups a work-item walks dozens of steps, and a step
+    // is load -> wait -> atomics; four words per load keep four times the bytes in flight (29 -> 17 us at 25 MPix)
+    const u4a* __restrict__ qr = reinterpret_cast<const u4a*>(pr);
+    const u4a* __restrict__ qg = reinterpret_cast<const u4a*>(pg);
+    const u4a* __restrict__ qb = reinterpret_cast<const u4a*>(pb);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const u4a r4 = qr[i], g4 = qg[i], b4 = qb[i];
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const unsigned r = r4[k2], g = g4[k2], b = b4[k2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(&mine[luma_bin((r >> (8 * j)) & 255u, (g >> (8 * j)) & 255u, (b >> (8 * j)) & 255u)], 1);
+        }
+    }
+    for (size_t i = n16 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {  // up to three words left over
         const unsigned r = pr[i], g = pg[i], b = pb[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) atomicAdd(&mine[luma_bin((r >> (8 * j)) & 255u, (g >> (8 * j)) & 255u, (b >> (8 * j)) & 255u)], 1);
@@ -3011,10 +3026,9 @@ __global__ __launch_bounds__(256) void k_equalize_apply4(uint8_t* __restrict__ i
     unsigned* __restrict__ pr = reinterpret_cast<unsigned*>(img);
     unsigned* __restrict__ pg = reinterpret_cast<unsigned*>(img + n);
     unsigned* __restrict__ pb = reinterpret_cast<unsigned*>(img + 2 * n);
-    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const unsigned wr = pr[i], wg = pg[i], wb = pb[i];
-        unsigned o_r = 0, o_g = 0, o_b = 0;
+    const size_t n4 = n / 4, n16 = n4 / 4, stride = (size_t)gridDim.x * blockDim.x;
+    auto word = [&](unsigned wr, unsigned wg, unsigned wb, unsigned& o_r, unsigned& o_g, unsigned& o_b) {
+        o_r = o_g = o_b = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned r = (wr >> (8 * j)) & 255u, g = (wg >> (8 * j)) & 255u, b = (wb >> (8 * j)) & 255u;
@@ -3034,9 +3048,30 @@ __global__ __launch_bounds__(256) void k_equalize_apply4(uint8_t* __restrict__ i
             o_g |= eg << (8 * j);
             o_b |= eb << (8 * j);
         }
-        pr[i] = o_r;
-        pg[i] = o_g;
-        pb[i] = o_b;
+    };
+    // sixteen pixels per step (dword-aligned 16-byte accesses), then the up to three words left over
+    u4a* __restrict__ qr = reinterpret_cast<u4a*>(pr);
+    u4a* __restrict__ qg = reinterpret_cast<u4a*>(pg);
+    u4a* __restrict__ qb = reinterpret_cast<u4a*>(pb);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const u4a r4 = qr[i], g4 = qg[i], b4 = qb[i];
+        u4a o_r, o_g, o_b;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            unsigned a, b, c;
+            word(r4[k2], g4[k2], b4[k2], a, b, c);
+            o_r[k2] = a, o_g[k2] = b, o_b[k2] = c;
+        }
+        qr[i] = o_r;
+        qg[i] = o_g;
+        qb[i] = o_b;
+    }
+    for (size_t i = n16 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        unsigned a, b, c;
+        word(pr[i], pg[i], pb[i], a, b, c);
+        pr[i] = a;
+        pg[i] = b;
+        pb[i] = c;
     }
 }
 
