@@ -1,5 +1,5 @@
 // libstitch_hip.so -- host side of the C ABI in include/stitch.h: argument checks, device workspace (plans),
-// launch sequencing on HIP streams, per-stage event timing.  All arithmetic is in stitch_kernels.hpp.
+// launch sequencing on HIP streams, per-stage event timing.  All arithmetic is in stitch_kernels.hpp (and the k_*.inc parts it includes).
 // Built for gfx950 only (hipcc --offload-arch=gfx950 -ffp-contract=off); there is no CPU path in this library.
 #include <hip/hip_runtime.h>
 

@@ -187,7 +187,7 @@ def test_equalize_lummix_finish(st, gpu, oracle, w, h):
 
 
 def test_equalize_every_colour(st, gpu, oracle):
-    """The equalisation and mix kernels evaluate the colour transforms of byte pixels in integers (stitch_kernels.hpp,
+    """The equalisation and mix kernels evaluate the colour transforms of byte pixels in integers (csrc/k_equalize.inc,
     ycc_terms): an image that holds each of the 2^24 colours once (plus a copy permuted so that the equalised partner of a
     pixel varies) must come out of equalise, mix and finish exactly as the oracle's double / float evaluation gives it; 4095
     columns wide as well, so that the byte kernels (plane size not a multiple of 4) see every colour too."""
@@ -405,7 +405,7 @@ def test_colour_transfer_degenerate(st, gpu, oracle):
 @pytest.mark.parametrize("negative", [False, True])
 def test_zero_tile_flags(st, gpu, oracle, no_zero_tiles, negative, monkeypatch):
     """Sparse canvases: where the fused sweep runs, all-(+0) tiles of the blur scratch are recorded in a flag instead of
-    being stored and re-read (ZeroTiles in stitch_kernels.hpp).  Same bits as the oracle with the flags on and off
+    being stored and re-read (ZeroTiles in csrc/k_compose.inc).  Same bits as the oracle with the flags on and off
     (STITCH_NO_ZERO_TILES=1), on canvases that are mostly empty for one image, with a frame that lies entirely inside
     a few tiles, and -- float frames -- with negative samples, whose decaying tails end in -0.0f (such tiles must not
     be taken for zero tiles)."""

@@ -291,7 +291,7 @@ def test_integer_luma_bin_is_exact(oracle):
 
 
 def test_integer_colour_transforms_are_exact(oracle):
-    """stitch_kernels.hpp evaluates RGB -> YCbCr (equalization.cpp:78-85, ImageProcess.cpp:242-244) and YCbCr -> RGB
+    """csrc/k_equalize.inc evaluates RGB -> YCbCr (equalization.cpp:78-85, ImageProcess.cpp:242-244) and YCbCr -> RGB
     (equalization.cpp:93-98) of BYTE inputs in integers: t = 299 R + 857 G + 114 B etc. (ycc_terms), the float value as
     (float)(t * 1e-k), the stored byte as t // 10^k, the way back as max(0, min(255, t // 10^k)).  Checked here for every one of
     the 2^24 inputs of either direction against the reference's double -> float -> clamp -> truncate expressions (the oracle's
