@@ -327,9 +327,9 @@ def test_integer_colour_transforms_are_exact(oracle):
             cb = (((128.0 - 0.168736 * Rf) - 0.331264 * Gf) + 0.5 * Bf).astype(np.float32)
             cr = (((128.0 + 0.5 * Rf) - 0.418688 * Gf) - 0.081312 * Bf).astype(np.float32)
             assert tcb.min() > 0 and tcr.min() > 0 and tcb.max() < 256000000 and tcr.max() < 256000000
-            assert np.array_equal((ty.astype(np.float64) * 0.001).astype(np.float32), y)
-            assert np.array_equal((tcb.astype(np.float64) * 1e-6).astype(np.float32), cb)
-            assert np.array_equal((tcr.astype(np.float64) * 1e-6).astype(np.float32), cr)
+            assert np.array_equal((ty.astype(np.float64) * 0.001).astype(np.float32), y) and np.array_equal(clamp(y), np.where(y < 256, y, np.float32(255)))
+            assert np.array_equal((tcb.astype(np.float64) * 1e-6).astype(np.float32), cb) and np.array_equal(clamp(cb), cb)
+            assert np.array_equal((tcr.astype(np.float64) * 1e-6).astype(np.float32), cr) and np.array_equal(clamp(cr), cr)
             assert np.array_equal(np.minimum(255, ty // 1000), clamp(y).astype(np.int64))
             assert np.array_equal(tcb // 1000000, clamp(cb).astype(np.int64))
             assert np.array_equal(tcr // 1000000, clamp(cr).astype(np.int64))
