@@ -1037,6 +1037,50 @@ bool words_ok(const void* base, size_t n) {
     return (n % 4) == 0 && (reinterpret_cast<uintptr_t>(base) % 4) == 0 && !std::getenv("STITCH_BYTE_KERNELS");
 }
 
+// The mix's divides by `den` as multiplications by its reciprocal plus one fma correction -- only where that is PROVEN equal for
+// every operand the kernels can meet (k_equalize.inc, MixK): Y and Yeq are floats (float)(t/1000) clamped, t = 0 .. 323850.
+// Both quotients of ImageProcess.cpp:261, a = Y*num and a = Yeq, are compared in both forms for all of them (~2 ms, once per
+// (num, den); the last few verdicts are kept).  STITCH_NO_FASTDIV=1: always divide.
+MixK mix_params(double num, double den) {
+    MixK k{num, den, 0.0};
+    static const bool off = std::getenv("STITCH_NO_FASTDIV") != nullptr;
+    if (off || !(den == den) || den == 0.0 || std::isinf(den) || !(num == num) || std::isinf(num)) return k;
+    struct Verdict {
+        double num, den;
+        bool ok;
+    };
+    static std::mutex mu;
+    static std::vector<Verdict> seen;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (const Verdict& v : seen)
+            if (std::memcmp(&v.num, &num, sizeof num) == 0 && std::memcmp(&v.den, &den, sizeof den) == 0) {
+                if (v.ok) k.rden = 1.0 / den;
+                return k;
+            }
+    }
+    const double rden = 1.0 / den;
+    auto quot = [&](double a) {
+        const double q = a * rden;
+        return std::fma(std::fma(-q, den, a), rden, q);
+    };
+    bool ok = std::isfinite(rden) && rden != 0.0;
+    for (unsigned t = 0; ok && t <= 323850u; ++t) {
+        float y = (float)((double)t * 0.001);
+        y = y < 256.f ? y : 255.f;
+        const double a1 = (double)y * num, a2 = (double)y;
+        const double d1 = a1 / den, d2 = a2 / den, f1 = quot(a1), f2 = quot(a2);
+        ok = std::memcmp(&d1, &f1, sizeof d1) == 0 && std::memcmp(&d2, &f2, sizeof d2) == 0;
+    }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (seen.size() >= 16) seen.erase(seen.begin());
+        seen.push_back(Verdict{num, den, ok});
+    }
+    if (ok) k.rden = rden;
+    return k;
+}
+
 int eq_grid(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g < 2048 ? (g ? g : 1) : 2048);  // memory-bound: cap the grid and stride (guide 6, guideline 11)
@@ -1065,14 +1109,14 @@ int dev_equalize_impl(uint8_t* d_img, int w, int h, int32_t* d_hist_out, bool fu
     k_lut<<<1, 256, 0, s>>>(hist, w, h, lut);
     if (fuse_mix) {
         if (v4)
-            k_equalize_apply4<true><<<eq_grid(n / 4), 256, 0, s>>>(d_img, n, lut, num, den);
+            k_equalize_apply4<true><<<eq_grid(n / 4), 256, 0, s>>>(d_img, n, lut, mix_params(num, den));
         else
-            k_equalize_apply<true><<<eq_grid(n), 256, 0, s>>>(d_img, n, lut, num, den);
+            k_equalize_apply<true><<<eq_grid(n), 256, 0, s>>>(d_img, n, lut, mix_params(num, den));
     } else {
         if (v4)
-            k_equalize_apply4<false><<<eq_grid(n / 4), 256, 0, s>>>(d_img, n, lut, 0.0, 1.0);
+            k_equalize_apply4<false><<<eq_grid(n / 4), 256, 0, s>>>(d_img, n, lut, MixK{0.0, 1.0, 0.0});
         else
-            k_equalize_apply<false><<<eq_grid(n), 256, 0, s>>>(d_img, n, lut, 0.0, 1.0);
+            k_equalize_apply<false><<<eq_grid(n), 256, 0, s>>>(d_img, n, lut, MixK{0.0, 1.0, 0.0});
     }
     if (d_hist_out) HIPCHK(hipMemcpyAsync(d_hist_out, hist, sizeof(int32_t) * 256, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipFreeAsync(scratch, s));
@@ -1570,7 +1614,7 @@ int stitch_dev_lummix_u8(uint8_t* d_result, const uint8_t* d_equalized, int w, i
     if (rc) return rc;
     if (!d_result || !d_equalized || w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "lummix: null buffer or bad size %dx%d", w, h);
     const size_t n = (size_t)w * h;
-    k_lummix<<<eq_grid(n), 256, 0, as_stream(stream)>>>(d_result, d_equalized, n, num, den);
+    k_lummix<<<eq_grid(n), 256, 0, as_stream(stream)>>>(d_result, d_equalized, n, mix_params(num, den));
     return launch_check("k_lummix");
 }
 

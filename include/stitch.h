@@ -156,6 +156,8 @@ int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
  *   STITCH_XBYF_SPIN_LIMIT=<n> polls before a hand-off wait of the fused sweep gives up (default 2^20; 0 forces the
  *                             bail-out path: tests of the sticky time-out report)
  *   STITCH_XBYF_EARLY=0       fused sweep: poll for the hand-off only when it is needed (default: read it ahead of the prefetch)
+ *   STITCH_NO_FASTDIV=1       luminance mix: always the IEEE divide (default: reciprocal + fma correction where the host has
+ *                             shown it equal for every operand the mix can meet, once per (num, den))
  *   STITCH_Y2=1               causal y sweep always with two columns per work-item (default: one column where a launch has
  *                             fewer than 1.5 wavefronts per SIMD)
  *   STITCH_RECOMPUTE=<0|1|2>  fused levels: 0 (default) = the causal x sweep writes its samples and the fused sweep reads

@@ -199,7 +199,10 @@ def test_equalize_every_colour(st, gpu, oracle):
     assert np.array_equal(hist, rhist) and np.array_equal(got, ref)
     other = np.ascontiguousarray(ref[:, ::-1, ::-1])  # every colour mixed with some other equalised colour
     assert np.array_equal(st.lummix(img, other), oracle.lummix(img, other))
-    assert np.array_equal(st.lummix(img, other, 7.0, 9.0), oracle.lummix(img, other, 7.0, 9.0))
+    # the mix divides by `den` through a reciprocal where the host has proven that equal for every possible operand, and by an
+    # IEEE divide otherwise (MixK): ordinary and odd parameter pairs alike must give the oracle's bytes
+    for num, den in [(7.0, 9.0), (3.0, 4.0), (3.7, 0.9), (1.0e-3, 7.0e5), (5.0, 3.0), (1.0, 1.0), (2.5, -3.0), (0.1, 0.3)]:
+        assert np.array_equal(st.lummix(img, other, num, den), oracle.lummix(img, other, num, den)), (num, den)
     fin, _ = st.finish(img)
     assert np.array_equal(fin, oracle.lummix(img, ref))
     odd = np.ascontiguousarray(img[:, :, :4095])
