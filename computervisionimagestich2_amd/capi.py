@@ -16,10 +16,10 @@ LIB_PATH = os.environ.get("STITCH_LIB", os.path.join(_HERE, "libstitch_hip.so"))
 
 # kernel ids of stitch_plan_read_profile -> the HIP kernel symbol each one times (rocprofv3 reports the same names)
 KERNELS = ("compose", "seam", "mask", "vv_x_fwd", "vv_x_bwd", "vv_y_fwd", "vv_y_bwd", "decimate", "collapse_top", "collapse",
-           "collapse_l0", "vv_xbyf")
-KERNEL_SYMBOLS = {"compose": "k_src_index (source-fused) / k_compose", "seam": "k_seam", "mask": "k_mask", "vv_x_fwd": "k_vv_x_fwd", "vv_x_bwd": "k_vv_x_bwd",
-                  "vv_y_fwd": "k_vv_y_fwd", "vv_y_bwd": "k_vv_y_bwd_dec", "decimate": "k_decimate", "collapse_top": "k_blend_top",
-                  "collapse": "k_collapse<float, false>", "collapse_l0": "k_collapse<T, true>", "vv_xbyf": "k_vv_xbyf<false, float, 0>"}
+           "collapse_l0", "vv_xbyf", "vv_x_fwd_src")
+KERNEL_SYMBOLS = {"compose": "k_src_index (source-fused) / k_compose", "seam": "k_seam", "mask": "k_mask", "vv_x_fwd": "k_vv_x_fwd<T, false, false>", "vv_x_bwd": "k_vv_x_bwd",
+                  "vv_y_fwd": "k_vv_y_fwd1 / k_vv_y_fwd", "vv_y_bwd": "k_vv_y_bwd_dec", "decimate": "k_decimate", "collapse_top": "k_blend_top",
+                  "collapse": "k_collapse<float, false>", "collapse_l0": "k_collapse<T, true>", "vv_xbyf": "k_vv_xbyf<false, float, 0>", "vv_x_fwd_src": "k_vv_x_fwd<T, true, false>"}
 
 
 class StitchError(RuntimeError):

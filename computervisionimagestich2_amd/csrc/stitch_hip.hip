@@ -330,7 +330,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             const int nb = (int)((lines + TS - 1) / TS);
             const bool rcmp = (p->recompute == 1 || (p->recompute == 2 && l >= 1)) && !(p->wf_dbg && l == 0);
             {
-                StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
+                StageTimer t(p, s, src && l == 0 ? STITCH_K_VV_X_FWD_SRC : STITCH_K_VV_X_FWD, l);
                 if (src && l == 0) {
                     if (rcmp)
                         k_vv_x_fwd<PX, true, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, p->ckpt);
@@ -392,7 +392,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             if (do_x) {
                 const int nb = (int)((lines + TS - 1) / TS);
                 {
-                    StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
+                    StageTimer t(p, s, src && l == 0 ? STITCH_K_VV_X_FWD_SRC : STITCH_K_VV_X_FWD, l);
                     if (src && l == 0)
                         k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, nullptr);
                     else
@@ -423,7 +423,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
         } else {
             HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * np, hipMemcpyDeviceToDevice, s));
             if (do_x) {
-                StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
+                StageTimer t(p, s, src && l == 0 ? STITCH_K_VV_X_FWD_SRC : STITCH_K_VV_X_FWD, l);
                 k_deriche<<<(int)((lines + 63) / 64), 64, 0, s>>>(p->T, p->T2, a.w, 1, a.pitch, a.h, a.ps, lines, p->drk);
             }
             if (do_y) {

@@ -51,12 +51,12 @@ def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample
     s3 = sum(4 * (10 * n[l] + 9 * n[l + 1]) for l in range(L - 1)) + 4 * 10 * n[L - 1]
     F = min(fused_sweep_levels, L - 1)
     m0 = 6 if implicit_mask else 7  # level-0 planes that exist as inputs of the blur
-    x_fwd = x_bwd = y_fwd = y_bwd = xbyf = 0
+    x_fwd = x_fwd_src = x_bwd = y_fwd = y_bwd = xbyf = 0
     for l in range(L - 1):
         rd = 4 * n[l] * (m0 if l == 0 else 7)
         wr = 4 * n[l] * 7
         if l == 0 and source_fused:
-            x_fwd += inputs + 4 * P + 4 * n[0] * m0  # frames + index plane in, six (or seven) x-swept planes out
+            x_fwd_src += inputs + 4 * P + 4 * n[0] * m0  # frames + index plane in, six (or seven) x-swept planes out
         else:
             x_fwd += rd + (4 * n[l] * m0 if l == 0 else wr)
         if l < F:
@@ -75,7 +75,7 @@ def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample
         "compose": 4 * P if source_fused else s1,  # source-fused: the index plane
         "seam": 2 * bytes_per_sample * level_w[0],  # two mid rows
         "mask": 0 if implicit_mask else 4 * P,
-        "vv_x_fwd": x_fwd, "vv_x_bwd": x_bwd, "vv_y_fwd": y_fwd, "vv_y_bwd": y_bwd, "vv_xbyf": xbyf,
+        "vv_x_fwd": x_fwd, "vv_x_fwd_src": x_fwd_src, "vv_x_bwd": x_bwd, "vv_y_fwd": y_fwd, "vv_y_bwd": y_bwd, "vv_xbyf": xbyf,
         "decimate": decimate,
         "collapse_top": 4 * 10 * n[L - 1],
         "collapse": sum(4 * (10 * n[l] + 9 * n[l + 1]) for l in range(1, L - 1)),

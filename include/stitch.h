@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STITCH_ABI_VERSION 2
+#define STITCH_ABI_VERSION 3
 
 typedef enum stitch_status {
     STITCH_OK = 0,
@@ -220,7 +220,8 @@ enum {
     STITCH_K_COLLAPSE = 9,     /* k_collapse<float,false>: expand + Laplacian + blend + collapse, levels 1..L-2  */
     STITCH_K_COLLAPSE_L0 = 10, /* k_collapse<T,true>: the same at level 0, writing the dense output canvas       */
     STITCH_K_VV_XBYF = 11,     /* k_vv_xbyf: anticausal-x + causal-y sweeps fused (row-band pipeline), finest levels */
-    STITCH_K_COUNT = 12
+    STITCH_K_VV_X_FWD_SRC = 12, /* k_vv_x_fwd<T,true>: the causal x sweep of a source-fused level 0 (reads the frames)  */
+    STITCH_K_COUNT = 13
 };
 int stitch_plan_set_profiling(stitch_plan *plan, int enabled);
 /* Record events only around launches of one kernel id (near-zero overhead inside a timed region). */

@@ -13,7 +13,7 @@ try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     c = d["config"]; k = d["kernels"]
     print(f"  {sys.argv[2]:10s} {d['value']:9.1f} MPix/s  ms/pair {c['ms_per_pair_per_gpu']:.4f}  one-seq {c['one_sequence_in_flight_ms_per_pair']:.4f}  verified {d['outputs_verified']}  "
-          + "  ".join(f"{n} {k[n]['ms_per_pair']:.4f}" for n in ("collapse_l0", "collapse", "vv_xbyf", "vv_x_fwd", "vv_y_bwd")))
+          + "  ".join(f"{n} {k[n]['ms_per_pair']:.4f}" for n in ("collapse_l0", "collapse", "vv_xbyf", "vv_x_fwd_src", "vv_x_fwd", "vv_y_bwd")))
 except Exception as e:
     print("  no result:", e)
 PY

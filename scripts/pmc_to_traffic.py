@@ -21,16 +21,16 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 steps_total = None  # derived below: k_seam runs once per step
 
 GROUP = {"k_compose": "compose", "k_src_index": "compose", "k_seam": "seam", "k_mask": "mask", "k_vv_x_fwd": "vv_x_fwd",
-         "k_vv_x_fwd<float, false>": "vv_x_fwd", "k_vv_x_fwd<float, true>": "vv_x_fwd", "k_vv_x_fwd<unsigned char, false>": "vv_x_fwd",
-         "k_vv_x_fwd<unsigned char, true>": "vv_x_fwd",
-         "k_vv_x_bwd": "vv_x_bwd", "k_vv_y_fwd": "vv_y_fwd", "k_vv_y_bwd_dec": "vv_y_bwd", "k_vv_y_bwd": "vv_y_bwd",
+         "k_vv_x_fwd<float, false>": "vv_x_fwd", "k_vv_x_fwd<float, true>": "vv_x_fwd_src", "k_vv_x_fwd<unsigned char, false>": "vv_x_fwd",
+         "k_vv_x_fwd<unsigned char, true>": "vv_x_fwd_src",
+         "k_vv_x_bwd": "vv_x_bwd", "k_vv_y_fwd": "vv_y_fwd", "k_vv_y_fwd1": "vv_y_fwd", "k_vv_y_bwd_dec": "vv_y_bwd", "k_vv_y_bwd": "vv_y_bwd",
          "k_decimate": "decimate", "k_collapse<float, false>": "collapse", "k_collapse<float, true>": "collapse_l0",
          "k_collapse<unsigned char, true>": "collapse_l0", "k_collapse4<float, false>": "collapse", "k_collapse4<float, true>": "collapse_l0",
          "k_collapse4<unsigned char, true>": "collapse_l0", "k_blend_top": "collapse_top", "k_vv_xbyf<false>": "vv_xbyf",
          "k_vv_xbyf<true>": "vv_xbyf"}
 # template arguments added later (CKPT of the causal sweep, pixel type and MODE of the fused sweep) do not change the group
-GROUP_PREFIX = {"k_vv_x_fwd<": "vv_x_fwd", "k_vv_xbyf<": "vv_xbyf"}
-LAUNCH_GROUPS = {"compose": 1, "seam": 1, "mask": 1, "vv_x_fwd": 11, "vv_x_bwd": 9, "vv_y_fwd": 9, "vv_y_bwd": 11, "decimate": 0,
+GROUP_PREFIX = {"k_vv_x_fwd<float, true": "vv_x_fwd_src", "k_vv_x_fwd<unsigned char, true": "vv_x_fwd_src", "k_vv_x_fwd<": "vv_x_fwd", "k_vv_xbyf<": "vv_xbyf"}
+LAUNCH_GROUPS = {"compose": 1, "seam": 1, "mask": 1, "vv_x_fwd": 10, "vv_x_fwd_src": 1, "vv_x_bwd": 9, "vv_y_fwd": 9, "vv_y_bwd": 11, "decimate": 0,
                  "collapse_top": 1, "collapse": 10, "collapse_l0": 1, "vv_xbyf": 2}  # config 2 with two fused-sweep levels
 
 

@@ -36,6 +36,9 @@ def test_algorithmic_bytes_match_survey():
     assert pk["vv_y_bwd"] == sum(7 * 4 * (n[l] + n[l + 1]) for l in range(11)) and pk["decimate"] == 0
     assert pk["vv_xbyf"] == 4 * n[0] * (6 + 7) + 4 * n[1] * 14
     assert pk["compose"] == 4 * n[0] and pk["mask"] == 0
+    # the source-fused causal sweep of level 0 is a kernel symbol (and id) of its own: frames + index plane in, six planes out
+    assert pk["vv_x_fwd_src"] == 2 * 4096 * 4096 * 3 * 4 + 4 * n[0] + 4 * n[0] * 6
+    assert pk["vv_x_fwd"] == sum(4 * n[l] * 14 for l in range(1, 11))
     inputs = 2 * 4096 * 4096 * 3 * 4
     assert pk["collapse_l0"] == inputs + 4 * n[0] + 4 * 9 * n[1] + 3 * 4 * n[0]
     assert sum(pk.values()) < 1.1 * st["total"]  # the fused design moves about what the canonical accounting counts
