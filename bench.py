@@ -5,7 +5,7 @@ Workload (the same at every N, so the N = 1, 2, 4, 8 lines are one strong-scalin
 --pairs-per-step (default 32) independent config-2 pairs -- BASELINE.json configs[3]: pair i = synthetic frames 2i+1
 (warped through the map with p[3] = -2048 - 8i) and 2i (the running mosaic), two 4096x4096x3 f32 frames ->
 6144x4096x3 f32 mosaic, warp + move + 12-level multi-band blend.  The batch is sharded contiguously over the ranks
-(pipeline.shard_range: 4 pairs per GPU on 8 ranks); a rank runs its shard as launch sequences of at most --batch (8)
+(pipeline.shard_range: 4 pairs per GPU on 8 ranks); a rank runs its shard as launch sequences of at most --batch (16)
 pairs on batched plans, up to --streams (4) sequences in flight on separate HIP streams, steps back to back with no
 host synchronisation between them.  Frames are generated on the device before the timed region: every input is
 resident in HBM when timing starts.
@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-step", type=int, default=32, help="pairs of one step over ALL ranks (32 = config 4's batch); "
                     "--pairs-per-step 4 on one GPU rehearses one rank's share of the 8-GPU run")
-    ap.add_argument("--batch", type=int, default=8, help="pairs per launch sequence (batched plan), at most")
+    ap.add_argument("--batch", type=int, default=16, help="pairs per launch sequence (batched plan), at most (the ABI's limit is 16)")
     ap.add_argument("--streams", type=int, default=4, help="launch sequences in flight per GPU, each on its own HIP stream")
     ap.add_argument("--frame", type=int, default=4096, help="frame edge (4096 = the metric's configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

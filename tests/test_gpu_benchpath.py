@@ -1,8 +1,8 @@
 """GPU: the code path bench.py times, compared with the oracle.
 
-bench.py runs batched plans of 8 config-4 pairs at 6144x4096: source-fused level 0, zero-tile and zero-index flags, the
-fused anticausal-x/causal-y sweep (k_vv_xbyf) on the two finest levels with 56 planes x 64 bands = 3584 bands per launch --
-more than the 2304 persistent workgroups, so workgroups come back to the band queue and claim a second band with their
+bench.py runs batched plans of 16 config-4 pairs at 6144x4096 (8 per rank on four GPUs, 4 on eight): source-fused level 0,
+zero-tile and zero-index flags, the fused anticausal-x/causal-y sweep (k_vv_xbyf) on the two finest levels with 112 planes x
+64 bands = 7168 bands per launch -- three times the 2304 persistent workgroups, so workgroups come back to the band queue and claim a second band with their
 LDS tile, speculation state and early-read state carried over.  The tests here run exactly that configuration against
 the oracle, force the many-bands-per-workgroup regime at small sizes in both pixel types, and check that a timed-out
 hand-off wait in ANY queued call is reported (the sticky fault count)."""
@@ -23,16 +23,17 @@ def _bench_items(capi, pipeline, torch, gpu, F, idx, tdt):
 
 
 def test_benchmarked_batch_full_size_against_oracle(st, gpu, oracle):
-    """Plan(6144, 4096, max_pairs=8) on config-4 pairs 0..7, f32 -- bench.py's lane 0 -- every output bit-compared with
-    oracle.pair; the same plan then runs pairs 24..31 (the workspace is reused as in the timed loop)."""
+    """Plan(6144, 4096, max_pairs=16) on config-4 pairs 0..15, f32 -- bench.py's lane 0 -- every output bit-compared with
+    oracle.pair; the same plan then runs pairs 16..31 (the workspace is reused as in the timed loop), and a plan of 8 (a
+    rank's share on four GPUs) pairs 8..15."""
     import torch
     from computervisionimagestich2_amd import capi, pipeline
-    F, B = 4096, 8
+    F, B = 4096, 16
     cw, ch = pipeline.config_canvas(F)
     plan = capi.Plan(cw, ch, max_pairs=B)
     assert plan.fused_sweep_levels == 2
     assert 7 * B * (ch // 64) > 2304  # more bands per launch than persistent workgroups: the re-claim path is taken
-    for idx in (range(0, 8), range(24, 32)):
+    for idx in (range(0, 16), range(16, 32)):
         items = _bench_items(capi, pipeline, torch, gpu, F, idx, torch.float32)
         for it in items:
             it[7].fill_(-1.0)
@@ -50,6 +51,15 @@ def test_benchmarked_batch_full_size_against_oracle(st, gpu, oracle):
             del fr, mo, ref, got
         del items
         torch.cuda.empty_cache()
+    plan.close()
+    plan = capi.Plan(cw, ch, max_pairs=8)  # the four-GPU share: 3584 bands per launch
+    items = _bench_items(capi, pipeline, torch, gpu, F, range(8, 16), torch.float32)
+    plan.pairs(items)
+    for q, i in enumerate(range(8, 16)):
+        plan.status(q)
+        if i in (8, 15):
+            rc, ref = oracle.pair(items[q][0].cpu().numpy(), items[q][1], 0.0, 0.0, items[q][4].cpu().numpy(), 0, 0, cw, ch)
+            assert rc == 0 and np.array_equal(items[q][7].cpu().numpy().view(np.uint32), ref.view(np.uint32)), i
     plan.close()
 
 
