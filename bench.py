@@ -112,8 +112,32 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+def self_launch(n, argv, worker=None, extra_env=None):
+    """`python3 bench.py --gpus N` without a launcher around it: start the N ranks as FRESH child processes (one per GPU,
+    `python -m torch.distributed.run`, rendezvous on 127.0.0.1) and hand back the launcher's exit status.  Rank 0's single
+    JSON line reaches stdout because the children inherit it (every other rank prints to stderr only).  Runs before
+    anything imports torch or touches HIP: this process never initialises the GPU, so nothing is exec'ed or forked from a
+    process that holds a device.  `worker` (tests): the script the ranks run instead of this file."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), worker or os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] --gpus {n} without WORLD_SIZE: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        assert "torch" not in sys.modules, "the launcher must run before torch is imported"
+        sys.exit(self_launch(args.gpus, sys.argv[1:], worker=os.environ.get("STITCH_BENCH_WORKER")))
     import torch
     import torch.distributed as dist
     from computervisionimagestich2_amd import capi, pipeline
