@@ -131,6 +131,18 @@ def device_count():
     return lib().stitch_device_count()
 
 
+def plan_cache_query(cw, ch, opts=None):
+    """(idle cached workspaces a host-buffer call for this canvas would take under the CURRENT environment's tuning
+    switches, fused_sweep_levels of the first) -- stitch_plan_cache_query."""
+    fused = C.c_int(-1)
+    n = _chk(lib().stitch_plan_cache_query(int(cw), int(ch), C.byref(_opts(opts)), C.byref(fused)))
+    return n, fused.value
+
+
+def trim():
+    lib().stitch_trim()
+
+
 def pyramid_levels(w, h, level_rule=0):
     lw, lh = (C.c_int * 32)(), (C.c_int * 32)()
     n = _chk(lib().stitch_pyramid_levels(int(w), int(h), int(level_rule), lw, lh))

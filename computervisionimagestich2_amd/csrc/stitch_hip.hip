@@ -184,6 +184,37 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
     return levels;
 }
 
+// Tuning / A-B switches of a plan (listed in include/stitch.h; none changes a result bit): ONE snapshot of the environment,
+// taken when a plan is created and again whenever a host-pointer entry point looks for an idle plan in the cache.  The
+// snapshot is part of the cache key (PlanKey), so a caller who flips a switch between two calls gets a workspace built for
+// the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
+struct Tuning {
+    int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
+        recompute, stamp;
+    static int env_int(const char* name) {
+        const char* e = std::getenv(name);
+        return e ? std::max(0, atoi(e)) : -1;
+    }
+    static Tuning from_env() {
+        Tuning t{};
+        t.wavefront = env_int("STITCH_WAVEFRONT");
+        t.no_fuse = std::getenv("STITCH_NO_FUSE") != nullptr;
+        t.no_src_fuse = env_int("STITCH_NO_SRC_FUSE") > 0;
+        t.no_zero_tiles = env_int("STITCH_NO_ZERO_TILES") > 0;
+        t.crows_l0 = env_int("STITCH_CROWS_L0");
+        t.crows_ln = env_int("STITCH_CROWS_LN");
+        t.collapse4 = env_int("STITCH_COLLAPSE4");
+        t.xbyf_wgs = env_int("STITCH_XBYF_WGS");
+        t.xbyf_spin_limit = env_int("STITCH_XBYF_SPIN_LIMIT");
+        t.xbyf_early = env_int("STITCH_XBYF_EARLY");
+        t.y2 = std::getenv("STITCH_Y2") != nullptr;
+        t.recompute = env_int("STITCH_RECOMPUTE");
+        t.stamp = std::getenv("STITCH_WAVEFRONT_STAMP") != nullptr;
+        return t;
+    }
+    bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
+};
+
 struct Level {
     int w, h, pitch;
     size_t ps;       // plane stride in floats = pitch*h
@@ -210,6 +241,7 @@ struct stitch_plan {
     int cap = 1;     // pairs per launch sequence this workspace can hold (planes of pair b follow pair b-1)
     int last_n = 0;  // pairs of the last call
     stitch_blend_opts opts{};
+    Tuning tune{};  // the environment's switches as they were when the plan was created
     Level lv[32]{};
     void* arena = nullptr;
     size_t arena_bytes = 0;
@@ -408,7 +440,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
                 {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
-                    if ((long)g.x * g.y < 1536 && !std::getenv("STITCH_Y2"))  // fewer than 1.5 wavefronts per SIMD: one column per work-item
+                    if ((long)g.x * g.y < 1536 && !p->tune.y2)  // fewer than 1.5 wavefronts per SIMD: one column per work-item
                         k_vv_y_fwd1<<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
                     else
                         k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
@@ -454,7 +486,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
         const Level& t = p->lv[L - 1];
         StageTimer tm(p, s, STITCH_K_COLLAPSE_TOP, L - 1);
         k_blend_top<<<grid_xy(t.pitch, t.h, n), 256, 0, s>>>(t.g, t.pitch, t.h, t.ps, t.e);
-        if (L == 1) k_emit_top<OUT><<<grid_xy(t.w, t.h, n), 256, 0, s>>>(t.e, t.w, t.h, t.pitch, t.ps, outs);
+        if (L == 1) k_emit_top<OUT><<<grid_xy(t.w, t.h, n), 256, 0, s>>>(t.e, t.w, t.h, t.pitch, t.ps, outs);  // writes out_u8 too
     }
     for (int l = L - 2; l >= 0; --l) {
         const Level& a = p->lv[l];
@@ -938,9 +970,10 @@ int host_move(const PX* src, int sw, int sh, int ox, int oy, PX* canvas, int cw,
 struct PlanKey {
     int dev, cw, ch;
     stitch_blend_opts o;
+    Tuning t;  // the tuning switches the plan was built under (Tuning): a changed environment never meets a stale plan
     bool operator==(const PlanKey& k) const {
         return dev == k.dev && cw == k.cw && ch == k.ch && o.sigma == k.o.sigma && o.blur_kind == k.o.blur_kind && o.level_rule == k.o.level_rule &&
-               o.seam_rule == k.o.seam_rule;
+               o.seam_rule == k.o.seam_rule && t == k.t;
     }
 };
 std::mutex g_plan_mu;
@@ -955,13 +988,14 @@ size_t plan_cache_limit() {
 struct PlanLease {
     stitch_plan* p = nullptr;
     PlanKey key{};
+    bool healthy = false;  // the leased call got as far as a status the plan survives (finish()); otherwise the plan is destroyed
     int acquire(int cw, int ch, const stitch_blend_opts* opts) {
         stitch_blend_opts o;
         stitch_blend_opts_default(&o);
         if (opts) o = *opts;
         int dev = 0;
         HIPCHK(hipGetDevice(&dev));
-        key = PlanKey{dev, cw, ch, o};
+        key = PlanKey{dev, cw, ch, o, Tuning::from_env()};
         {
             std::lock_guard<std::mutex> g(g_plan_mu);
             for (auto it = g_idle_plans.begin(); it != g_idle_plans.end(); ++it)
@@ -973,21 +1007,27 @@ struct PlanLease {
         }
         return stitch_plan_create(cw, ch, opts, &p);
     }
+    // outcome of the leased call's stitch_plan_status: a failed seam scan leaves the workspace as good as before
+    int finish(int rc) {
+        healthy = rc == STITCH_OK || rc == STITCH_ERR_EMPTY_MIDROW || rc == STITCH_ERR_ZERO_OVERLAP;
+        return rc;
+    }
     ~PlanLease() {
         if (!p) return;
+        // wait for the plan's last call and acknowledge its faults BEFORE the cache mutex is taken: other threads' host-pointer
+        // calls only ever block on the list operations below, never on this plan's GPU work
+        const bool keep = healthy && plan_cache_limit() > 0 && stitch_plan_clear_fault(p) == STITCH_OK;
         std::vector<stitch_plan*> evict;
-        {
+        if (keep) {
             std::lock_guard<std::mutex> g(g_plan_mu);
-            if (plan_cache_limit() > 0 && stitch_plan_clear_fault(p) == STITCH_OK) {  // waits for the plan's last call
-                g_idle_plans.emplace_front(key, p);
-                p = nullptr;
-                while (g_idle_plans.size() > plan_cache_limit()) {
-                    evict.push_back(g_idle_plans.back().second);
-                    g_idle_plans.pop_back();
-                }
+            g_idle_plans.emplace_front(key, p);
+            p = nullptr;
+            while (g_idle_plans.size() > plan_cache_limit()) {
+                evict.push_back(g_idle_plans.back().second);
+                g_idle_plans.pop_back();
             }
         }
-        if (p) stitch_plan_destroy(p);
+        if (p) stitch_plan_destroy(p);  // a call that failed part-way (or a timed-out hand-off) never goes back into the cache
         for (auto* e : evict) stitch_plan_destroy(e);
     }
 };
@@ -1005,7 +1045,7 @@ int host_blend(const PX* a, const PX* b, int w, int h, const stitch_blend_opts* 
     H2D(da.p, a, bytes);
     H2D(db.p, b, bytes);
     if ((rc = dev_blend<PX>(pg.p, da.as<PX>(), db.as<PX>(), dout.as<PX>(), nullptr))) return rc;
-    if ((rc = stitch_plan_status(pg.p, seam_out))) return rc;
+    if ((rc = pg.finish(stitch_plan_status(pg.p, seam_out)))) return rc;
     D2H(out, dout.p, bytes);
     return STITCH_OK;
 }
@@ -1027,7 +1067,7 @@ int host_pair(const PX* frame, int fw, int fh, const double pm[8], float offx, f
     H2D(dm.p, mosaic, mb);
     if ((rc = dev_pair<PX>(pg.p, df.as<PX>(), fw, fh, pm, offx, offy, dm.as<PX>(), mw, mh, ox, oy, dout.as<PX>(), nullptr)))
         return rc;
-    if ((rc = stitch_plan_status(pg.p, seam_out))) return rc;
+    if ((rc = pg.finish(stitch_plan_status(pg.p, seam_out)))) return rc;
     D2H(out, dout.p, ob);
     return STITCH_OK;
 }
@@ -1139,7 +1179,7 @@ int dev_step(const PX* d_frame, int fw, int fh, const double p_fwd[8], const dou
     PlanLease lease;  // idle workspace of this canvas size, or a new one; goes back to the cache when the step is done
     if ((rc = lease.acquire(g.cw, g.ch, opts))) return rc;
     if ((rc = dev_pair<PX>(lease.p, d_frame, fw, fh, p_bwd, g.min_x, g.min_y, d_mosaic, mw, mh, g.ox, g.oy, d_out, stream))) return rc;
-    return stitch_plan_status(lease.p, seam_out);
+    return lease.finish(stitch_plan_status(lease.p, seam_out));
 }
 
 }  // namespace
@@ -1180,6 +1220,23 @@ void stitch_trim(void) {
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
         (void)hipMemPoolTrimTo(pool, 0);
     (void)hipGetLastError();
+}
+
+int stitch_plan_cache_query(int cw, int ch, const stitch_blend_opts* opts, int* fused_sweep_levels) {
+    stitch_blend_opts o;
+    stitch_blend_opts_default(&o);
+    if (opts) o = *opts;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    const PlanKey key{dev, cw, ch, o, Tuning::from_env()};
+    int n = 0;
+    std::lock_guard<std::mutex> g(g_plan_mu);
+    for (auto& e : g_idle_plans)
+        if (e.first == key) {
+            if (n == 0 && fused_sweep_levels) *fused_sweep_levels = e.second->wf_levels;
+            ++n;
+        }
+    return n;
 }
 
 void stitch_blend_opts_default(stitch_blend_opts* o) {
@@ -1316,7 +1373,9 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     p->opts = o;
     p->vvk = make_vvk(o.sigma);
     p->drk = make_drk(o.sigma);
-    p->no_fuse = std::getenv("STITCH_NO_FUSE") != nullptr;
+    const Tuning tn = Tuning::from_env();
+    p->tune = tn;
+    p->no_fuse = tn.no_fuse != 0;
     p->blur_skip = o.blur_kind == 0 ? (o.sigma < 0.5f) : (o.sigma < 0.1f);  // CImg.h:35051 / :34800
     if (hipGetDevice(&p->device) != hipSuccess) {
         delete p;
@@ -1351,14 +1410,14 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     const size_t t2_off = o.blur_kind == 1 ? take(t_bytes) : 0;
     // wavefront sweep: enabled with STITCH_WAVEFRONT=<levels> (Van Vliet only); granule buffers sized for level 0
     int wf_levels = 0;
-    if (const char* e = std::getenv("STITCH_WAVEFRONT"))
-        wf_levels = std::max(0, std::min(4, std::atoi(e)));
+    if (tn.wavefront >= 0)
+        wf_levels = std::min(4, tn.wavefront);
     else if (max_pairs >= 2 || 7L * ((lh[0] + TS - 1) / TS) >= 800)
         // auto: the band pipeline pays where a launch has many bands in flight (planes x 64-row bands of level 0: 896 for two
         // 6144x4096 pairs, 1792 for one 24576x16384 pair) to hide its fill (bands x hand-off latency) and the levels have
         // enough tiles to stream; a lone 6144x4096 pair (448 bands) is faster unfused
         while (wf_levels < 2 && wf_levels < L - 1 && lw[wf_levels] >= 1024 && lh[wf_levels] >= 1024) ++wf_levels;
-    if (o.blur_kind != 0 || std::getenv("STITCH_NO_FUSE") || o.sigma < 0.5f) wf_levels = 0;
+    if (o.blur_kind != 0 || tn.no_fuse || o.sigma < 0.5f) wf_levels = 0;
     wf_levels = std::min(wf_levels, L - 1);
     while (wf_levels > 0 && (lw[wf_levels - 1] < 2 || lh[wf_levels - 1] < 2)) --wf_levels;
     const int NC0 = (v0.w + TS - 1) / TS;
@@ -1367,7 +1426,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     const size_t zi_off = take((size_t)B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS));
     const size_t zt_off = wf_levels ? take((size_t)7 * B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS)) : 0;
     int recompute = 0;  // opt-in: level 0 re-run from the frames measured 3 % slower, the plane levels within noise
-    if (const char* e = std::getenv("STITCH_RECOMPUTE")) recompute = wf_levels > 0 ? std::max(0, std::min(2, atoi(e))) : 0;
+    if (tn.recompute >= 0) recompute = wf_levels > 0 ? std::min(2, tn.recompute) : 0;
     const size_t ck_off = recompute ? take(sizeof(double) * 3 * NC0 * 7 * B * (size_t)(v0.h + 64)) : 0;
     // x-sweep state [4][lines] followed by the y state the wavefront kernel leaves [4][planes][pitch]
     const size_t state_n = 4 * 7 * B * (size_t)(v0.h + 64) + 4 * 7 * B * (size_t)std::max(v0.h + 64, v0.pitch);
@@ -1405,28 +1464,26 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         p->zi = reinterpret_cast<uint8_t*>(base + zi_off);
         p->recompute = recompute;
         if (recompute) p->ckpt = reinterpret_cast<double*>(base + ck_off);
-        if (const char* ew = std::getenv("STITCH_XBYF_WGS")) p->wf_max_wgs = std::max(1, atoi(ew));
-        if (const char* es = std::getenv("STITCH_XBYF_SPIN_LIMIT")) p->wf_spin_limit = (unsigned)std::max(0, atoi(es));
+        if (tn.xbyf_wgs >= 0) p->wf_max_wgs = std::max(1, tn.xbyf_wgs);
+        if (tn.xbyf_spin_limit >= 0) p->wf_spin_limit = (unsigned)tn.xbyf_spin_limit;
         // diagnostic build: one record per persistent workgroup, sized from the workgroup count actually used
-        if (std::getenv("STITCH_WAVEFRONT_STAMP") &&
+        if (tn.stamp &&
             (hipMalloc((void**)&p->wf_dbg, sizeof(unsigned long long) * (size_t)p->wf_max_wgs * 8) != hipSuccess ||
              hipMemset(p->wf_dbg, 0, sizeof(unsigned long long) * (size_t)p->wf_max_wgs * 8) != hipSuccess)) {
             (void)hipGetLastError();
             p->wf_dbg = nullptr;
         }
-        if (const char* ee = std::getenv("STITCH_XBYF_EARLY")) p->wf_early_read = atoi(ee) != 0;
-        const char* ez = std::getenv("STITCH_NO_ZERO_TILES");  // A/B and tests: move the zeros like any other sample
-        p->zero_tiles = !(ez && atoi(ez) != 0);
+        if (tn.xbyf_early >= 0) p->wf_early_read = tn.xbyf_early != 0;
+        p->zero_tiles = !tn.no_zero_tiles;  // A/B and tests: move the zeros like any other sample
     }
     p->side = reinterpret_cast<float*>(base + side_off);
     // implicit level-0 mask: needs both Van Vliet sweeps at level 0 and 64-row blocks that do not straddle planes
     p->mask_opt = !p->no_fuse && o.blur_kind == 0 && !p->blur_skip && L >= 2 && v0.w > 1 && v0.h > 1 && (v0.h % 64) == 0;
     {
-        if (const char* c = getenv("STITCH_CROWS_L0")) p->crows_l0 = std::max(1, atoi(c));
-        if (const char* c = getenv("STITCH_CROWS_LN")) p->crows_ln = std::max(1, atoi(c));
-        if (const char* c = getenv("STITCH_COLLAPSE4")) p->collapse4 = atoi(c) != 0;
-        const char* e = getenv("STITCH_NO_SRC_FUSE");  // A/B and tests: keep S1 as its own kernel (k_compose)
-        p->src_fuse = p->mask_opt && !(e && atoi(e) != 0);
+        if (tn.crows_l0 >= 0) p->crows_l0 = std::max(1, tn.crows_l0);
+        if (tn.crows_ln >= 0) p->crows_ln = std::max(1, tn.crows_ln);
+        if (tn.collapse4 >= 0) p->collapse4 = tn.collapse4 != 0;
+        p->src_fuse = p->mask_opt && !tn.no_src_fuse;  // STITCH_NO_SRC_FUSE: A/B and tests, keep S1 as its own kernel (k_compose)
     }
     // the slack rows and pitch padding are read by partial tiles: give them defined (zero) contents once
     if (hipMemset(p->arena, 0, off) != hipSuccess || hipHostMalloc((void**)&p->h_seam, sizeof(SeamDev) * B) != hipSuccess) {
@@ -1520,7 +1577,8 @@ int stitch_dev_pair_f32(stitch_plan* plan, const float* d_frame, int fw, int fh,
 
 int stitch_plan_status_at(stitch_plan* p, int index, stitch_seam* seam_out) {
     if (!p) return fail(STITCH_ERR_ARG, "null plan");
-    if (index < 0 || index >= p->cap) return fail(STITCH_ERR_ARG, "status: index %d outside the plan's capacity %d", index, p->cap);
+    if (index < 0 || index >= std::max(1, p->last_n))
+        return fail(STITCH_ERR_ARG, "status: index %d outside the %d pair(s) of the plan's last call", index, p->last_n);
     if (p->pending) {
         HIPCHK(hipStreamSynchronize(p->last_stream));
         p->pending = false;

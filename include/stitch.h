@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STITCH_ABI_VERSION 3
+#define STITCH_ABI_VERSION 4
 
 typedef enum stitch_status {
     STITCH_OK = 0,
@@ -73,6 +73,11 @@ void stitch_blend_opts_default(stitch_blend_opts *o);
  * device, canvas size and options (STITCH_PLAN_CACHE=<n> idle plans, default 8, 0 = none) and their device staging
  * buffers in the device's stream-ordered memory pool.  stitch_trim() releases all of it (current device). */
 void stitch_trim(void);
+/* Number of idle cached workspaces that a host-buffer call for this canvas and these options would take NOW -- the key is
+ * (device, canvas, options, the tuning switches of the environment as they are at this moment: see "Tuning / A-B switches"
+ * below), so a caller who changes a switch between two calls never meets a workspace built under the old setting.
+ * fused_sweep_levels (optional) receives stitch_plan_fused_sweep_levels of the first match.  Negative on error. */
+int stitch_plan_cache_query(int cw, int ch, const stitch_blend_opts *opts, int *fused_sweep_levels);
 /* Pyramid shape for a canvas (ImageProcess.cpp:675-676,705-708).  Returns the level count (>0) or a status;
  * level_w/level_h (capacity 32) may be NULL. */
 int stitch_pyramid_levels(int w, int h, int level_rule, int *level_w, int *level_h);
@@ -143,7 +148,9 @@ int stitch_plan_levels(const stitch_plan *plan, int *level_w, int *level_h);
  * STITCH_WAVEFRONT=<n> levels when that environment variable is set (0 = always separate sweeps).  Results are
  * identical either way. */
 int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
-/* Tuning / A-B switches read at plan creation (none of them changes a result bit):
+/* Tuning / A-B switches, read from the environment when a plan is created (none of them changes a result bit).  The
+ * host-buffer entry points read them again on every call and key their workspace cache on the values, so a switch that
+ * changes between two calls takes effect at once:
  *   STITCH_WAVEFRONT=<n>      fused sweep on exactly n finest levels (0 = never)
  *   STITCH_NO_FUSE=1          blur and decimation as separate kernels, level-0 mask materialised
  *   STITCH_NO_SRC_FUSE=1      materialise level 0 (k_compose) instead of gathering it from the frames where it is needed
@@ -187,13 +194,15 @@ typedef struct stitch_pair_desc {
     void *out;
     void *out_u8;       /* _f32 calls only, optional (NULL = none): a second copy of the mosaic as unsigned char --
                            the reference's own output type, CImg<unsigned char>(CImg<float>), C-cast truncation
-                           (ImageProcess.cpp:772) -- written by the same kernel (what a sharded batch gathers)       */
+                           (ImageProcess.cpp:772) -- written by the same kernel (what a sharded batch gathers); single-level
+                           pyramids included                                                                            */
 } stitch_pair_desc;
 int stitch_dev_pairs_u8(stitch_plan *plan, const stitch_pair_desc *pairs, int n, void *stream);
 int stitch_dev_pairs_f32(stitch_plan *plan, const stitch_pair_desc *pairs, int n, void *stream);
 /* Waits for the plan's last call to finish and reports its outcome: STITCH_OK, STITCH_ERR_EMPTY_MIDROW or
  * STITCH_ERR_ZERO_OVERLAP for the seam scan of pair `index` of the LAST call (in these cases the output buffer holds
- * unspecified finite values), or STITCH_ERR_HIP when a hand-off wait of the fused sweep (k_vv_xbyf) timed out.  The
+ * unspecified finite values), or STITCH_ERR_HIP when a hand-off wait of the fused sweep (k_vv_xbyf) timed out (index must be below the
+ * last call's n: STITCH_ERR_ARG otherwise).  The
  * time-out is STICKY: the plan counts timed-out waits in a device word that no launch sequence clears, so a bail-out in
  * ANY call queued on the plan since the last stitch_plan_clear_fault is reported here (the outputs of every call since
  * then are invalid), not just one in the last call. */

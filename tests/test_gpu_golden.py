@@ -291,6 +291,28 @@ def test_uint8_copy_of_float_mosaics(st, gpu, oracle):
             assert rc == 0 and np.array_equal(it[7].cpu().numpy().view(np.uint32), ref.view(np.uint32))
             assert np.array_equal(it[8].cpu().numpy(), ref.astype(np.uint8)) and torch.equal(it[8], capi.dev_quantize(it[7]))
         plan.close()
+    # a single-level pyramid (3 x 2 canvas): the result is the top-level blend itself, out_u8 is written there too; and the
+    # status of a pair beyond the LAST call's n is refused instead of answering with an earlier call's record
+    plan = capi.Plan(3, 2, max_pairs=2)
+    assert plan.levels == 1
+    A, B = oracle.synth(3, 2, 0, np.float32), oracle.synth(3, 2, 1, np.float32)
+    P = [1.0, 0.0, 0.0, -1.0, 0.0, 1.0, 0.0, 0.0]
+    mk = lambda: (torch.from_numpy(B).to(gpu), P, 0.0, 0.0, torch.from_numpy(A).to(gpu), 0, 0,
+                  torch.empty((3, 2, 3), dtype=torch.float32, device=gpu), torch.full((3, 2, 3), 7, dtype=torch.uint8, device=gpu))
+    items = [mk(), mk()]
+    plan.pairs(items)
+    plan.status(1)
+    rc, ref = oracle.pair(B, P, 0.0, 0.0, A, 0, 0, 3, 2)
+    assert rc == 0
+    for it in items:
+        assert np.array_equal(it[7].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        assert np.array_equal(it[8].cpu().numpy(), ref.astype(np.uint8))
+    plan.pairs(items[:1])
+    plan.status(0)
+    with pytest.raises(st.StitchError) as e:
+        plan.status(1)  # pair 1 belongs to the call before the last one
+    assert e.value.code == st.capi.ERR_ARG
+    plan.close()
 
 
 def test_config5_size_single_gpu_against_oracle(st, gpu, oracle):

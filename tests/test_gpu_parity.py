@@ -248,10 +248,20 @@ def test_blend_random_sizes_sweep(st, gpu, oracle):
 def test_fused_sweep_modes_agree(st, gpu, oracle, mode, dtype, monkeypatch):
     """STITCH_WAVEFRONT=<n>: anticausal-x + causal-y sweeps fused (row-band pipeline with inter-workgroup hand-offs)
     for the n finest levels, or kept as separate kernels (0).  Same bits either way; sizes exercise partial bands
-    and column blocks, the implicit level-0 mask (h % 64 == 0) and the materialised one."""
+    and column blocks, the implicit level-0 mask and the materialised one.
+    The host entry point takes its workspace from a cache: the tuning switches are part of the cache key, so the plan
+    that ran MUST be one built under this mode -- asserted through stitch_plan_cache_query (which looks the workspace up
+    under the current environment) right after the call, with other modes' plans for the same sizes already cached."""
     from computervisionimagestich2_amd import capi
+    sizes = [(700, 448), (333, 250), (1200, 128), (130, 2050 // 2)]
+    other = "1" if mode != "1" else "0"
+    monkeypatch.setenv("STITCH_WAVEFRONT", other)  # plans of ANOTHER mode for the same sizes sit in the cache first
+    A, B = two_canvases(oracle, 700, 448, 3, 4, dtype)
+    st.blend(A, B)
+    n_other, fused_other = capi.plan_cache_query(700, 448)
+    assert n_other >= 1 and fused_other == min(int(other), 9 - 1)
     monkeypatch.setenv("STITCH_WAVEFRONT", mode)
-    for (w, h) in [(700, 448), (333, 250), (1200, 128), (130, 2050 // 2)]:
+    for (w, h) in sizes:
         A, B = two_canvases(oracle, w, h, 3, 4, dtype)
         rc, ref, rs = oracle.blend(A, B)
         if rc != 0:
@@ -259,6 +269,10 @@ def test_fused_sweep_modes_agree(st, gpu, oracle, mode, dtype, monkeypatch):
         got, s = st.blend(A, B)
         assert s.as_tuple() == rs.as_tuple()
         assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (mode, w, h)
+        n, fused = capi.plan_cache_query(w, h)
+        levels = capi.pyramid_levels(w, h)[0]
+        assert n >= 1, "the plan that just ran is not cached under the current switches: a stale plan was used"
+        assert fused == min(int(mode), levels - 1), (mode, w, h, fused)
     plan = capi.Plan(700, 448)
     assert plan.fused_sweep_levels == min(int(mode), plan.levels - 1)
     plan.close()
