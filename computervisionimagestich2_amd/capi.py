@@ -79,6 +79,7 @@ def lib():
         L.stitch_last_error.restype = C.c_char_p
         L.stitch_plan_workspace_bytes.restype = C.c_size_t
         L.stitch_plan_workspace_bytes.argtypes = [C.c_void_p]
+        L.stitch_plan_fast_paths.argtypes = [C.c_void_p]
         L.stitch_plan_destroy.restype = None
         L.stitch_plan_destroy.argtypes = [C.c_void_p]
         L.stitch_blend_opts_default.restype = None
@@ -467,6 +468,13 @@ class Plan:
     @property
     def levels(self):
         return len(self.level_w)
+
+    @property
+    def fast_paths(self):
+        """stitch_plan_fast_paths as a set of names."""
+        f = lib().stitch_plan_fast_paths(self._h)
+        names = ("implicit_mask", "source_fused", "fused_sweep", "zero_tiles", "fused_decimate")
+        return {n for i, n in enumerate(names) if f & (1 << i)}
 
     @property
     def workspace_bytes(self):

@@ -190,7 +190,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp;
+        recompute, stamp, gate64;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -210,6 +210,7 @@ struct Tuning {
         t.y2 = std::getenv("STITCH_Y2") != nullptr;
         t.recompute = env_int("STITCH_RECOMPUTE");
         t.stamp = std::getenv("STITCH_WAVEFRONT_STAMP") != nullptr;
+        t.gate64 = env_int("STITCH_GATE64") > 0;
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -351,27 +352,34 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
         }
         const bool wavefront = p->opts.blur_kind == 0 && do_x && do_y && l < p->wf_levels;
         // zero-tile flags: only where all three users run (causal x sweep, fused sweep, fused anticausal-y + decimation)
+        const int NR = (a.h + TS - 1) / TS;  // 64-row bands per plane, the last one possibly partial
         ZeroTiles zt{};
-        if (wavefront && p->zero_tiles && (a.h % TS) == 0 && a.h / TS <= 256 && (a.w & 1) == 0 && !p->no_fuse) {
+        if (wavefront && p->zero_tiles && NR <= 256 && (a.w & 1) == 0 && !p->no_fuse && !(p->tune.gate64 && a.h % TS)) {
             zt.flags = p->zt;
             zt.h = a.h;
-            zt.NR = a.h / TS;
+            zt.NR = NR;
             zt.NC = (a.w + TS - 1) / TS;
         }
+        // blocks of the x sweeps: per-plane bands wherever a block's treatment depends on its plane (implicit mask, source-fused
+        // level 0, zero-tile flags), 64 stacked lines otherwise (fewer blocks when planes are shorter than 64 rows)
+        Bands bd{};
+        if (mk.enabled || (src && l == 0) || zt.flags) bd = Bands{NR, a.h};
+        const int nbx = bd.nr ? np * bd.nr : (int)((lines + TS - 1) / TS);
+        const bool rowz = zt.flags && (a.h % YCH) != 0;  // fused anticausal-y + decimation: a chunk of rows may straddle bands
         if (wavefront) {
-            const int nb = (int)((lines + TS - 1) / TS);
+            const int nb = nbx;
             const bool rcmp = (p->recompute == 1 || (p->recompute == 2 && l >= 1)) && !(p->wf_dbg && l == 0);
             {
                 StageTimer t(p, s, src && l == 0 ? STITCH_K_VV_X_FWD_SRC : STITCH_K_VV_X_FWD, l);
                 if (src && l == 0) {
                     if (rcmp)
-                        k_vv_x_fwd<PX, true, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, p->ckpt);
+                        k_vv_x_fwd<PX, true, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, p->ckpt, bd);
                     else
-                        k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, nullptr);
+                        k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, nullptr, bd);
                 } else if (rcmp)
-                    k_vv_x_fwd<PX, false, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{}, p->ckpt);
+                    k_vv_x_fwd<PX, false, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{}, p->ckpt, bd);
                 else
-                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{}, nullptr);
+                    k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{}, nullptr, bd);
             }
             Wavefront wf{};
             wf.yg = p->wf_yg;
@@ -379,7 +387,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             wf.abort = p->wf_ctrl + WF_CTRL_WORDS - 16;
             wf.sticky = p->wf_ctrl + WF_CTRL_WORDS;
             wf.spin_limit = p->wf_spin_limit;
-            wf.NR = (a.h + TS - 1) / TS;
+            wf.NR = NR;
             wf.NC = (a.w + TS - 1) / TS;
             wf.NP = np;
             // every polled word is cleared in front of the launch (never told apart by a per-launch argument: a captured
@@ -416,23 +424,26 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
             dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
             if ((a.w & 1) == 0 && !p->no_fuse) {
-                k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
+                if (rowz)
+                    k_vv_y_bwd_dec<true><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
+                else
+                    k_vv_y_bwd_dec<false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
                 decimated = true;
             } else
                 k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, state_y, nullptr, nullptr);
         } else if (p->opts.blur_kind == 0) {
             if (do_x) {
-                const int nb = (int)((lines + TS - 1) / TS);
+                const int nb = nbx;
                 {
                     StageTimer t(p, s, src && l == 0 ? STITCH_K_VV_X_FWD_SRC : STITCH_K_VV_X_FWD, l);
                     if (src && l == 0)
-                        k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, nullptr);
+                        k_vv_x_fwd<PX, true><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, pa, zt, zi, nullptr, bd);
                     else
-                        k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{}, nullptr);
+                        k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{}, nullptr, bd);
                 }
                 {
                     StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
-                    k_vv_x_bwd<<<nb, 64, 0, s>>>(p->T, a.w, a.pitch, lines, p->vvk, p->state, mk);
+                    k_vv_x_bwd<<<nb, 64, 0, s>>>(p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
                 }
             } else
                 HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * np, hipMemcpyDeviceToDevice, s));
@@ -447,7 +458,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 }
                 StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
                 if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
-                    k_vv_y_bwd_dec<<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
+                    k_vv_y_bwd_dec<false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
                     decimated = true;
                 } else
                     k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, nullptr, nullptr);
@@ -507,7 +518,9 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
             CollapseArgs<OUT, true> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, outs,
                                       a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, p->crows_l0, xa, xb};
             const int strips = (a.h + p->crows_l0 - 1) / p->crows_l0;
-            if (xb > xa)
+            if (xb > xa && src && pa.a_dense)
+                k_collapse4<OUT, true, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
+            else if (xb > xa)
                 k_collapse4<OUT, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
             else
                 k_collapse<OUT, true><<<grid_xy(cols, strips, n), 256, 0, s>>>(A);
@@ -551,26 +564,59 @@ int check_plan_call(stitch_plan* p, const void* a, const void* b, const void* ou
     return STITCH_OK;
 }
 
+// The launch sequence of n pairs (or of one dense-canvas blend, pa.a_dense): S1, seam scan, REDUCE, collapse.
+template <typename PX>
+int run_pairs(stitch_plan* p, const PairArgs<PX>& pa, const OutPtrs<PX>& outs, int n, hipStream_t s, bool src) {
+    const Level& a = p->lv[0];
+    int rc;
+    // source-fused: level 0 is a function of the inputs, evaluated by its three consumers (a warped frame through an index
+    // plane, dense images as pure shifts)
+    ZeroTiles zi{};
+    if (src && p->zero_tiles && !pa.a_dense) {
+        zi.flags = p->zi;
+        zi.h = a.h;
+        zi.NR = (a.h + TS - 1) / TS;
+        zi.NC = (a.w + TS - 1) / TS;
+    }
+    {
+        StageTimer t(p, s, STITCH_K_COMPOSE, 0);
+        if (src) {
+            if (!pa.a_dense) {
+                if (zi.flags) k_fill_bytes<<<64, 256, 0, s>>>(zi.flags, (size_t)n * zi.NR * zi.NC, (uint8_t)1);
+                k_src_index<PX><<<grid_xy(a.pitch, (a.h + SI_ROWS - 1) / SI_ROWS, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps, zi);
+            }
+        } else if (pa.a_dense)
+            k_load_canvases<PX><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(pa.frame[0], pa.mosaic[0], a.g, a.w, a.h, a.pitch, a.ps);
+        else
+            k_compose<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps, 0);
+    }
+    if ((rc = run_seam_mask<PX>(p, n, s, pa, src))) return rc;
+    if ((rc = run_reduce<PX>(p, n, s, pa, src, zi))) return rc;
+    if ((rc = run_collapse<PX>(p, n, outs, s, pa, src))) return rc;
+    p->last_stream = s;
+    p->pending = true;
+    p->last_n = n;
+    return STITCH_OK;
+}
+
+// blendTwoImages on two dense canvases: a pair whose "frame" is canvas a as it stands and whose "mosaic" is canvas b with a
+// zero shift (PairArgs::a_dense).  Source-fused plans read both canvases where level 0 is needed -- no level-0 planes, no mask
+// plane, no index plane; otherwise k_load_canvases materialises level 0.
 template <typename PX>
 int dev_blend(stitch_plan* p, const PX* d_a, const PX* d_b, PX* d_out, void* stream) {
     int rc = check_plan_call(p, d_a, d_b, d_out);
     if (rc) return rc;
-    hipStream_t s = as_stream(stream);
-    const Level& a = p->lv[0];
-    {
-        StageTimer t(p, s, STITCH_K_COMPOSE, 0);
-        k_load_canvases<PX><<<grid_xy(a.pitch, a.h), 256, 0, s>>>(d_a, d_b, a.g, a.w, a.h, a.pitch, a.ps);
-    }
-    const PairArgs<PX> none{};  // dense canvases: level 0 is in memory
-    if ((rc = run_seam_mask<PX>(p, 1, s, none, false))) return rc;
-    if ((rc = run_reduce<PX>(p, 1, s, none, false, ZeroTiles{}))) return rc;
+    PairArgs<PX> pa{};
+    pa.frame[0] = d_a;
+    pa.mosaic[0] = d_b;
+    pa.out[0] = d_out;
+    pa.fw[0] = pa.mw[0] = p->cw;
+    pa.fh[0] = pa.mh[0] = p->ch;
+    pa.a_dense = 1;
     OutPtrs<PX> outs{};
     outs.p[0] = d_out;
-    if ((rc = run_collapse<PX>(p, 1, outs, s, none, false))) return rc;
-    p->last_stream = s;
-    p->pending = true;
-    p->last_n = 1;
-    return STITCH_OK;
+    const bool src = p->src_fuse && (unsigned long long)p->cw * p->ch * sizeof(PX) < 0xfffffff0ULL;  // 32-bit byte offsets into a channel plane
+    return run_pairs<PX>(p, pa, outs, 1, as_stream(stream), src);
 }
 
 // n independent pairs (n <= plan capacity) through one launch sequence: every kernel covers all n pairs.
@@ -602,36 +648,10 @@ int dev_pairs(stitch_plan* p, const stitch_pair_desc* d, int n, void* stream) {
         pa.offx[i] = d[i].offx;
         pa.offy[i] = d[i].offy;
     }
-    hipStream_t s = as_stream(stream);
-    const Level& a = p->lv[0];
-    int rc;
-    // source-fused: level 0 is a function of the frames, evaluated by its three consumers through an index plane
     bool src = p->src_fuse;
-    ZeroTiles zi{};
-    if (src && p->zero_tiles) {
-        zi.flags = p->zi;
-        zi.h = a.h;
-        zi.NR = a.h / TS;
-        zi.NC = (a.w + TS - 1) / TS;
-    }
     for (int i = 0; i < n; ++i)  // 32-bit element indices and byte offsets into one channel plane
         src = src && (unsigned long long)d[i].fw * d[i].fh * sizeof(PX) < 0xfffffff0ULL && (unsigned long long)d[i].mw * d[i].mh * sizeof(PX) < 0xfffffff0ULL;
-    {
-        StageTimer t(p, s, STITCH_K_COMPOSE, 0);
-        if (src) {
-            if (zi.flags) k_fill_bytes<<<64, 256, 0, s>>>(zi.flags, (size_t)n * zi.NR * zi.NC, (uint8_t)1);
-            k_src_index<PX><<<grid_xy(a.pitch, (a.h + SI_ROWS - 1) / SI_ROWS, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps, zi);
-        }
-        else
-            k_compose<PX><<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(pa, a.g, a.w, a.h, a.pitch, a.ps, 0);
-    }
-    if ((rc = run_seam_mask<PX>(p, n, s, pa, src))) return rc;
-    if ((rc = run_reduce<PX>(p, n, s, pa, src, zi))) return rc;
-    if ((rc = run_collapse<PX>(p, n, outs, s, pa, src))) return rc;
-    p->last_stream = s;
-    p->pending = true;
-    p->last_n = n;
-    return STITCH_OK;
+    return run_pairs<PX>(p, pa, outs, n, as_stream(stream), src);
 }
 
 template <typename PX>
@@ -1477,8 +1497,9 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         p->zero_tiles = !tn.no_zero_tiles;  // A/B and tests: move the zeros like any other sample
     }
     p->side = reinterpret_cast<float*>(base + side_off);
-    // implicit level-0 mask: needs both Van Vliet sweeps at level 0 and 64-row blocks that do not straddle planes
-    p->mask_opt = !p->no_fuse && o.blur_kind == 0 && !p->blur_skip && L >= 2 && v0.w > 1 && v0.h > 1 && (v0.h % 64) == 0;
+    // implicit level-0 mask: needs both Van Vliet sweeps at level 0 (the x sweeps then run per-plane bands, Bands, at any height;
+    // STITCH_GATE64=1 restores the old restriction to heights that are multiples of 64 for A/B runs)
+    p->mask_opt = !p->no_fuse && o.blur_kind == 0 && !p->blur_skip && L >= 2 && v0.w > 1 && v0.h > 1 && !(tn.gate64 && v0.h % 64);
     {
         if (tn.crows_l0 >= 0) p->crows_l0 = std::max(1, tn.crows_l0);
         if (tn.crows_ln >= 0) p->crows_ln = std::max(1, tn.crows_ln);
@@ -1614,6 +1635,18 @@ int stitch_plan_clear_fault(stitch_plan* p) {
 }
 
 int stitch_plan_capacity(const stitch_plan* p) { return p ? p->cap : 0; }
+int stitch_plan_fast_paths(const stitch_plan* p) {
+    if (!p) return 0;
+    int f = 0;
+    if (p->mask_opt) f |= STITCH_FAST_IMPLICIT_MASK;
+    if (p->src_fuse) f |= STITCH_FAST_SOURCE_FUSED;
+    if (p->wf_levels > 0) f |= STITCH_FAST_FUSED_SWEEP;
+    if (p->wf_levels > 0 && p->zero_tiles && !p->no_fuse && (p->lv[0].w & 1) == 0 && (p->lv[0].h + TS - 1) / TS <= 256 &&
+        !(p->tune.gate64 && p->lv[0].h % TS))
+        f |= STITCH_FAST_ZERO_TILES;
+    if (!p->no_fuse && p->opts.blur_kind == 0 && !p->blur_skip && p->L >= 2 && (p->lv[0].w & 1) == 0 && p->lv[0].h > 1) f |= STITCH_FAST_FUSED_DECIMATE;
+    return f;
+}
 int stitch_plan_fused_sweep_levels(const stitch_plan* p) { return p ? p->wf_levels : 0; }
 
 int stitch_dev_pairs_u8(stitch_plan* plan, const stitch_pair_desc* pairs, int n, void* stream) {

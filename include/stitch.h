@@ -148,6 +148,23 @@ int stitch_plan_levels(const stitch_plan *plan, int *level_w, int *level_h);
  * STITCH_WAVEFRONT=<n> levels when that environment variable is set (0 = always separate sweeps).  Results are
  * identical either way. */
 int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
+/* Which of the forms that avoid HBM round trips this plan's level 0 runs with (a bit mask; results never depend on it):
+ *   IMPLICIT_MASK   the level-0 mask (a vertical step, ImageProcess.cpp:690-698) is generated where it is needed, never stored
+ *   SOURCE_FUSED    level 0 of a and b is read from the caller's frames / canvases by its consumers, never materialised
+ *                   (pairs: through an index plane of the warp; stitch_dev_blend_*: the dense canvases themselves)
+ *   FUSED_SWEEP     anticausal-x and causal-y sweeps of the finest levels run as one kernel (stitch_plan_fused_sweep_levels)
+ *   ZERO_TILES      all-zero 64x64 tiles of the blur scratch are flagged instead of stored (level 0; needs FUSED_SWEEP)
+ *   FUSED_DECIMATE  level 0's anticausal y sweep writes the decimated level directly (even canvas widths)
+ * IMPLICIT_MASK and SOURCE_FUSED hold for every canvas size with the Van Vliet blur (blur_kind 0, sigma >= 0.5) and at least
+ * two pyramid levels. */
+enum {
+    STITCH_FAST_IMPLICIT_MASK = 1,
+    STITCH_FAST_SOURCE_FUSED = 2,
+    STITCH_FAST_FUSED_SWEEP = 4,
+    STITCH_FAST_ZERO_TILES = 8,
+    STITCH_FAST_FUSED_DECIMATE = 16
+};
+int stitch_plan_fast_paths(const stitch_plan *plan);
 /* Tuning / A-B switches, read from the environment when a plan is created (none of them changes a result bit).  The
  * host-buffer entry points read them again on every call and key their workspace cache on the values, so a switch that
  * changes between two calls takes effect at once:
@@ -163,6 +180,8 @@ int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
  *   STITCH_XBYF_SPIN_LIMIT=<n> polls before a hand-off wait of the fused sweep gives up (default 2^20; 0 forces the
  *                             bail-out path: tests of the sticky time-out report)
  *   STITCH_XBYF_EARLY=0       fused sweep: poll for the hand-off only when it is needed (default: read it ahead of the prefetch)
+ *   STITCH_GATE64=1           implicit level-0 mask, source fusion and zero-tile flags only for level heights that are multiples
+ *                             of 64 (the round-2 behaviour; A/B runs)
  *   STITCH_NO_FASTDIV=1       luminance mix: always the IEEE divide (default: reciprocal + fma correction where the host has
  *                             shown it equal for every operand the mix can meet, once per (num, den))
  *   STITCH_Y2=1               causal y sweep always with two columns per work-item (default: one column where a launch has

@@ -21,7 +21,8 @@ def run(seed, N, verbose=True):
 
 
 SWITCHES = {"STITCH_WAVEFRONT": [None, "0", "1", "2"], "STITCH_RECOMPUTE": [None, "1", "2"], "STITCH_Y2": [None, "1"],
-            "STITCH_COLLAPSE4": [None, "0"], "STITCH_NO_ZERO_TILES": [None, "1"], "STITCH_NO_SRC_FUSE": [None, "1"]}
+            "STITCH_COLLAPSE4": [None, "0"], "STITCH_NO_ZERO_TILES": [None, "1"], "STITCH_NO_SRC_FUSE": [None, "1"],
+            "STITCH_GATE64": [None, None, "1"]}
 
 
 def _case(case, rng, O, capi, torch, dev, bad, done, verbose):
@@ -48,6 +49,35 @@ def _case(case, rng, O, capi, torch, dev, bad, done, verbose):
             opts = dict(sigma=float(rng.choice([0.3, 0.8, 1.5, 2.0, 3.5])), blur_kind=int(rng.integers(0, 2)), level_rule=int(rng.integers(0, 2)),
                         seam_rule=int(rng.integers(0, 2)))
         plan = capi.Plan(cw, ch, opts=opts, max_pairs=B)
+        if general and rng.random() < 0.25:
+            # stitch_dev_blend_*: two dense canvases (what blendTwoImages gets), each empty on one side -- the same plan, the
+            # dense-pair form of the source-fused level 0 (or k_load_canvases under the switches that materialise it)
+            A, Bc = O.synth(cw, ch, 2 * case, dtype), O.synth(cw, ch, 2 * case + 1, dtype)
+            ca, cb = sorted(int(v) for v in rng.integers(0, cw + 1, 2))
+            if rng.random() < 0.5:
+                A[:, :, cb:] = 0
+                Bc[:, :, :ca] = 0
+            else:
+                A[:, :, :ca] = 0
+                Bc[:, :, cb:] = 0
+            if rng.random() < 0.3:  # ragged holes: rows of zeros across a canvas (the middle row may become empty)
+                r0 = int(rng.integers(0, ch))
+                A[:, r0:r0 + int(rng.integers(1, 40)), :] = 0
+            rc, ref, rs = O.blend(A, Bc, opts)
+            out = plan.blend(torch.from_numpy(A).to(dev), torch.from_numpy(Bc).to(dev))
+            try:
+                seam = plan.status(0)
+                grc = 0
+            except capi.StitchError as e:
+                grc = e.code
+            if grc != rc:
+                print("BLEND STATUS MISMATCH", case, grc, rc); bad += 1
+            elif rc == 0:
+                done += 1
+                if seam.as_tuple() != rs.as_tuple() or not np.array_equal(out.cpu().numpy().view(np.uint8), ref.view(np.uint8)):
+                    print("BLEND MISMATCH", case, (cw, ch, dtype.__name__), {k: os.environ.get(k) for k in SWITCHES}, opts); bad += 1
+            plan.close()
+            return bad, done
         items, refs = [], []
         for i in range(B):
             fw, fh = int(rng.integers(40, cw)), int(rng.integers(40, ch + 60))
