@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-single", action="store_true", help="skip the single-pair-in-flight latency measurement")
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the finished mosaics on their ranks (no exchange at all)")
     ap.add_argument("--no-verify", action="store_true", help="skip the output comparison (status() checks stay)")
+    ap.add_argument("--no-coalesce", action="store_true", help="one launch sequence per step even when a rank's share of a step is "
+                    "smaller than --batch (default: consecutive steps' shares are launched together, up to --batch pairs)")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -190,56 +192,78 @@ def main():
     B = min(args.batch, n_local)
     seqs = pipeline.batches_of(P, rank, world, B)  # [(first, last+1)] global pair indices, one launch sequence each
     nb = len(seqs)
-    S = max(1, min(args.streams, nb * max(K, 1)))
+    # A shard smaller than a launch sequence (8 GPUs: 4 pairs per rank and step): the shares of G consecutive steps go into ONE
+    # launch sequence of G * n_local pairs -- steps run back to back without host synchronisation anyway, every step keeps its own
+    # output buffers and its own gather -- so that a rank's launches are as long as the single-GPU run's (the fused sweep's fill
+    # and the coarse levels' launches are paid once per sequence, not once per 4 pairs).  --no-coalesce: one sequence per step.
+    G = max(1, args.batch // n_local) if (nb == 1 and not args.no_coalesce) else 1
+    G = min(G, max(K, 1))
+    S = max(1, min(args.streams, -(-nb * max(K, 1) // G)))
     pair_in = {}
     for i in range(lo, hi):
         pair_in[i] = (capi.dev_synth(F, F, 2 * i + 1, tdt, dev), pipeline.config_map(i, F), 0.0, 0.0,
                       capi.dev_synth(F, F, 2 * i, tdt, dev), 0, 0)
     lanes = []
     for ln in range(S):
-        lanes.append({"plan": capi.Plan(cw, ch, max_pairs=B), "stream": torch.cuda.Stream(device=dev),
-                      "outs": [[torch.empty((3, ch, cw), dtype=tdt, device=dev) for _ in range(B)] for _ in range(2)],
+        lanes.append({"plan": capi.Plan(cw, ch, max_pairs=B * G), "stream": torch.cuda.Stream(device=dev),
+                      "outs": [[torch.empty((3, ch, cw), dtype=tdt, device=dev) for _ in range(B * G)] for _ in range(2)],
                       "holds": [None, None], "last": None})
     plan = lanes[0]["plan"]
     gather = None
     if use_gather:
         # finished mosaics travel as unsigned char through pipeline.MosaicGather -- the class the gloo tests cover; one block
         # of n_max mosaics per rank and step, two steps of buffers so that the gather of step k overlaps the kernels of k+1
-        gather = pipeline.MosaicGather((n_max, 3, ch, cw), dev, world, rank, slots=2, force_collective=True)
+        gather = pipeline.MosaicGather((n_max, 3, ch, cw), dev, world, rank, slots=2 * G, force_collective=True)
         gstream = torch.cuda.Stream(device=dev)
 
-    def run_seq(c, seq, gather_step=None, n=None):
-        """Launch sequence number c (a global counter picks lane and output slot) over global pairs seq = (first, last+1)."""
+    def run_seq(c, seq, gather_steps=None, n=None, copies=1):
+        """Launch sequence number c (a global counter picks lane and output slot) over global pairs seq = (first, last+1),
+        `copies` times over (the shares of that many consecutive steps in one sequence); gather_steps: the step numbers whose
+        gather blocks receive the unsigned char mosaics, one per copy."""
         ln, slot = c % S, (c // S) % 2
         L = lanes[ln]
-        idx = list(range(seq[0], seq[1]))[:n]
+        idx = list(range(seq[0], seq[1]))[:n] * copies
+        per = len(idx) // copies
         with torch.cuda.stream(L["stream"]):
             outs = L["outs"][slot]
-            if gather_step is None:
+            if gather_steps is None:
                 L["plan"].pairs([pair_in[i] + (outs[q],) for q, i in enumerate(idx)])
             else:
-                blk = gather.input_slot(gather_step)  # waits (on this stream) for the gather that last used the buffers
+                blks = [gather.input_slot(st_) for st_ in gather_steps]  # waits (on this stream) for the gathers that last used the buffers
                 if tdt == torch.float32:  # the unsigned char copy that travels is written by the level-0 collapse itself (out_u8)
-                    L["plan"].pairs([pair_in[i] + (outs[q], blk[i - lo]) for q, i in enumerate(idx)])
+                    L["plan"].pairs([pair_in[i] + (outs[q], blks[q // per][i - lo]) for q, i in enumerate(idx)])
                 else:
                     L["plan"].pairs([pair_in[i] + (outs[q],) for q, i in enumerate(idx)])
                     for q, i in enumerate(idx):
-                        blk[i - lo].copy_(outs[q])
+                        blks[q // per][i - lo].copy_(outs[q])
             L["holds"][slot] = idx
             L["last"] = slot
-            if gather_step is not None:
+            if gather_steps is not None:
                 ev = torch.cuda.Event()
                 ev.record(L["stream"])
                 return ev
         return None
 
-    def step(k, with_gather):
-        evs = [run_seq(k * nb + j, seqs[j], k if with_gather else None) for j in range(nb)]
-        if with_gather:
-            with torch.cuda.stream(gstream):
-                for ev in evs:
-                    gstream.wait_event(ev)
-                gather.submit(k)  # asynchronous: runs on RCCL's stream behind gstream
+    def run_steps(k0, count, with_gather):
+        """Steps k0 .. k0+count-1: launch sequences of the rank's shard; when the shard is small, up to G consecutive steps'
+        shares per sequence.  The sequences are cut in step order (the gathers are submitted in step order on every rank) and
+        balanced: their number is rounded up to a multiple of the lanes, so that the lanes finish together instead of one
+        sequence running on alone at the end (20 steps, G = 4, 4 lanes: 3+3+3+3+2+2+2+2, not 4+4+4+4+4)."""
+        m = -(-count // G)
+        if G > 1 and m > S and m % S:
+            m = min(-(-m // S) * S, count)
+        sizes = [count // m + (1 if i < count % m else 0) for i in range(m)] if count > 0 else []
+        k = k0
+        for i, g in enumerate(sizes):
+            steps_ = list(range(k, k + g))
+            evs = [run_seq((k0 // G + i) * nb + j, seqs[j], steps_ if with_gather else None, copies=g) for j in range(nb)]
+            if with_gather:
+                with torch.cuda.stream(gstream):
+                    for ev in evs:
+                        gstream.wait_event(ev)
+                    for st_ in steps_:
+                        gather.submit(st_)  # asynchronous: runs on RCCL's stream behind gstream
+            k += g
 
     def drain():
         if gather is not None:
@@ -248,13 +272,12 @@ def main():
         torch.cuda.synchronize()
 
     def timed(fn, steps):
-        """`steps` x fn(k), bracketed by barrier + synchronize on both sides; max over ranks."""
+        """fn(steps) = exactly `steps` steps of work, bracketed by barrier + synchronize on both sides; max over ranks."""
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in range(steps):
-            fn(k)
+        fn(steps)
         drain()
         if use_dist:
             dist.barrier()
@@ -304,7 +327,7 @@ def main():
             mine = torch.tensor([ref_q.get(lo + j, 0) for j in range(n_max)], dtype=torch.int64, device=dev)
             allq = torch.empty(world * n_max, dtype=torch.int64, device=dev)
             dist.all_gather_into_tensor(allq, mine)
-            got = gather.out[gather_step % 2]
+            got = gather.out[gather_step % gather.slots]
             for r in range(world):
                 rlo, rhi = pipeline.shard_range(P, r, world)
                 for j in range(rhi - rlo):
@@ -315,10 +338,15 @@ def main():
                         checks["bad"].append(f"{tag}: gathered mosaic of rank {r}, pair {rlo + j}: checksum differs")
         checks["regions"] += 1
 
+    def log(msg):
+        if args.verbose:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     # ---- warm-up ---------------------------------------------------------------------------------------------------
-    for k in range(W):
-        step(k, use_gather)
+    log(f"warm-up: {W} step(s), {n_local} pairs per step, {G} step(s) per launch sequence, {S} lane(s)")
+    run_steps(0, W, use_gather)
     drain()
+    log("warm-up done")
     verify("warm-up", (W - 1) if (use_gather and W > 0) else None)
 
     # pilot (lane 0, every launch bracketed by HIP events; ~10 % overhead, so never the timed region): per-kernel
@@ -327,32 +355,39 @@ def main():
     plan.read_profile()
     PILOT = 3
     for k in range(PILOT):
-        run_seq(k * S, seqs[0])
+        run_seq(k * S, seqs[0], copies=G)
     torch.cuda.synchronize()
     pilot = plan.read_profile()
     dom = max(pilot, key=lambda k_: pilot[k_][0])
     plan.set_profiling(False)
 
+    log("pilot done")
     # timed region 1 -> `value`: every launch sequence of K steps in flight over S streams (+ the exchange, N > 1)
-    elapsed = timed(lambda k: step(k, use_gather), K)
+    elapsed = timed(lambda n_: run_steps(0, n_, use_gather), K)
     verify("region 1", (K - 1) if use_gather else None)
     elapsed_noex = None
     if use_gather:
-        elapsed_noex = timed(lambda k: step(k, False), K)
+        elapsed_noex = timed(lambda n_: run_steps(0, n_, False), K)
         verify("region 1 (no exchange)")
 
+    log("region 1 done")
     # timed region 2 -> `roofline`: ONE sequence in flight (kernels do not overlap, so a launch's duration is the kernel's
     # own), HIP events around the dominant kernel's launches only, on the launch stream
     if not args.no_kernel_events:
         plan.set_profiling_kernel(dom)
     plan.read_profile()
-    elapsed_one = timed(lambda k: run_seq(k * S, seqs[0]), K)
+    def one_lane(n_):
+        for k in range(n_):
+            run_seq(k * S, seqs[0], copies=G)
+
+    elapsed_one = timed(one_lane, K)
     prof = plan.read_profile()
     plan.set_profiling(False)
     verify("region 2")
     seam = plan.status(0)
-    n_seq0 = seqs[0][1] - seqs[0][0]
+    n_seq0 = (seqs[0][1] - seqs[0][0]) * G
 
+    log("region 2 done")
     # single pair in flight (config 2 as a latency figure)
     single_ms = None
     if world == 1 and not args.no_single:
@@ -378,7 +413,7 @@ def main():
         src_fused = ch % 64 == 0 and os.environ.get("STITCH_NO_SRC_FUSE") is None and os.environ.get("STITCH_NO_FUSE") is None
         per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, px_bytes, plan.fused_sweep_levels,
                                                         fused_decimate=os.environ.get("STITCH_NO_FUSE") is None, source_fused=src_fused,
-                                                        implicit_mask=src_fused)
+                                                        implicit_mask=src_fused, coarse_from=plan.coarse_from)
         line = {
             "metric": "warp+blend MPix/s at 4096x4096x3 f32" if args.pixel == "f32" else "warp+blend MPix/s at 4096x4096x3 u8", "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
@@ -387,10 +422,11 @@ def main():
             "data": "synthetic", "outputs_verified": verified, "n_ranks_seen": n_ranks_seen,
             "config": {"workload": f"config 2 pairs ({F}x{F}x3 {args.pixel} frames -> {cw}x{ch}x3 {args.pixel} mosaic: warp + move + "
                                    f"{plan.levels}-level multi-band blend), {P} independent pairs per step (config 4's batch) sharded contiguously "
-                                   f"over {world} rank(s): {n_local} pairs per rank per step as {nb} launch sequence(s) of {B} on batched plans, "
+                                   f"over {world} rank(s): {n_local} pairs per rank per step as {nb} launch sequence(s) of {B}"
+                                   + (f" (the shares of {G} consecutive steps launched together: {B * G} pairs per sequence)" if G > 1 else "") + " on batched plans, "
                                    f"{S} sequences in flight per GPU on separate HIP streams; canvas pixels counted",
                        "frame": [F, F, 3], "canvas": [cw, ch, 3], "levels": plan.levels, "pairs_per_step": P, "pairs_per_rank_per_step": n_local,
-                       "pairs_per_sequence": B, "sequences_in_flight": S, "fused_sweep_levels": plan.fused_sweep_levels,
+                       "pairs_per_sequence": B * G, "steps_per_sequence": G, "sequences_in_flight": S, "fused_sweep_levels": plan.fused_sweep_levels,
                        "mpix_per_pair": round(mpix_pair, 3),
                        "ms_per_pair_per_gpu": round(elapsed / K / n_local * 1e3, 4),
                        "one_sequence_in_flight_ms_per_pair": round(elapsed_one / K / n_seq0 * 1e3, 4),
@@ -459,6 +495,19 @@ def main():
                             "owned_bytes_per_pair_all_kernels": sum(per_kernel.values())}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_frame, args.verbose)
+            # the reference's OWN loop on the same pair (unsigned char frames, one thread: ~2 minutes, so not inside this run):
+            # timed once on a GPU box's host by scripts/bench_reference_config2.py, which also compares the MI355X result with it
+            rpath = os.path.join(ROOT, "profiles", "r03_reference_config2.json")
+            if os.path.exists(rpath) and F == 4096:
+                try:
+                    rj = json.load(open(rpath))
+                    line["cpu_baseline_reference"] = {"value": rj["value"], "unit": rj["unit"], "cores": rj["cores"], "kind": "reference", "measured_offline": True,
+                                                      "sample": f"the reference's warpingImageByHomography + movingImageByOffset + blendTwoImages ({rj['reference_lines']}) "
+                                                                f"compiled in place, config 2's pair with unsigned char frames, {rj['total_s']} s on one thread of a GPU box's "
+                                                                "host (profiles/r03_reference_config2.json, scripts/bench_reference_config2.py)",
+                                                      "mi355x_bit_identical": rj.get("mi355x_same_pair", {}).get("bit_identical_to_the_reference")}
+                except Exception:
+                    pass
         print(json.dumps(line), flush=True)
     for L in lanes:
         L["plan"].close()

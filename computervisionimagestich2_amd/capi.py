@@ -16,10 +16,11 @@ LIB_PATH = os.environ.get("STITCH_LIB", os.path.join(_HERE, "libstitch_hip.so"))
 
 # kernel ids of stitch_plan_read_profile -> the HIP kernel symbol each one times (rocprofv3 reports the same names)
 KERNELS = ("compose", "seam", "mask", "vv_x_fwd", "vv_x_bwd", "vv_y_fwd", "vv_y_bwd", "decimate", "collapse_top", "collapse",
-           "collapse_l0", "vv_xbyf", "vv_x_fwd_src")
+           "collapse_l0", "vv_xbyf", "vv_x_fwd_src", "coarse")
 KERNEL_SYMBOLS = {"compose": "k_src_index (source-fused) / k_compose", "seam": "k_seam", "mask": "k_mask", "vv_x_fwd": "k_vv_x_fwd<T, false, false>", "vv_x_bwd": "k_vv_x_bwd",
                   "vv_y_fwd": "k_vv_y_fwd1 / k_vv_y_fwd", "vv_y_bwd": "k_vv_y_bwd_dec", "decimate": "k_decimate", "collapse_top": "k_blend_top",
-                  "collapse": "k_collapse<float, false>", "collapse_l0": "k_collapse<T, true>", "vv_xbyf": "k_vv_xbyf<false, float, 0>", "vv_x_fwd_src": "k_vv_x_fwd<T, true, false>"}
+                  "collapse": "k_collapse<float, false>", "collapse_l0": "k_collapse<T, true>", "vv_xbyf": "k_vv_xbyf<false, float, 0>", "vv_x_fwd_src": "k_vv_x_fwd<T, true, false>",
+                  "coarse": "k_coarse"}
 
 
 class StitchError(RuntimeError):
@@ -80,6 +81,7 @@ def lib():
         L.stitch_plan_workspace_bytes.restype = C.c_size_t
         L.stitch_plan_workspace_bytes.argtypes = [C.c_void_p]
         L.stitch_plan_fast_paths.argtypes = [C.c_void_p]
+        L.stitch_plan_coarse_from.argtypes = [C.c_void_p]
         L.stitch_plan_destroy.restype = None
         L.stitch_plan_destroy.argtypes = [C.c_void_p]
         L.stitch_blend_opts_default.restype = None
@@ -470,10 +472,14 @@ class Plan:
         return len(self.level_w)
 
     @property
+    def coarse_from(self):
+        return lib().stitch_plan_coarse_from(self._h)
+
+    @property
     def fast_paths(self):
         """stitch_plan_fast_paths as a set of names."""
         f = lib().stitch_plan_fast_paths(self._h)
-        names = ("implicit_mask", "source_fused", "fused_sweep", "zero_tiles", "fused_decimate")
+        names = ("implicit_mask", "source_fused", "fused_sweep", "zero_tiles", "fused_decimate", "coarse_levels")
         return {n for i, n in enumerate(names) if f & (1 << i)}
 
     @property

@@ -190,7 +190,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp, gate64;
+        recompute, stamp, gate64, coarse, single_fast;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -211,6 +211,8 @@ struct Tuning {
         t.recompute = env_int("STITCH_RECOMPUTE");
         t.stamp = std::getenv("STITCH_WAVEFRONT_STAMP") != nullptr;
         t.gate64 = env_int("STITCH_GATE64") > 0;
+        t.coarse = env_int("STITCH_COARSE");
+        t.single_fast = env_int("STITCH_SINGLE_FAST");
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -278,6 +280,8 @@ struct stitch_plan {
     int crows_ln = 0;  // 0 = per level, crows_of()
     int crows_l0 = 4 * CROWS;
     bool collapse4 = true;  // four columns per work-item in the collapse where possible (STITCH_COLLAPSE4=0: always k_collapse)
+    unsigned long long* co_dbg = nullptr;  // STITCH_COARSE_STAMP=1: k_coarse's phase stamps of the last launch (diagnostics)
+    int coarse_from = 0;  // > 0: levels coarse_from .. L-1 run in ONE launch (k_coarse: REDUCE to the top, top blend, collapse back up)
     bool src_fuse = false;  // pairs: level-0 planes evaluated from the frames by their consumers, k_compose never runs
     SeamDev* d_seam = nullptr;
     SeamDev* h_seam = nullptr;  // pinned
@@ -337,7 +341,8 @@ template <typename PX>
 int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, bool src, const ZeroTiles& zi) {
     const int np = 7 * n;  // planes in flight: every launch covers all pairs of the batch
     if (p->wf_levels > 0) k_clear_words<<<1, 256, 0, s>>>((u64*)p->wf_ctrl, WF_CTRL_WORDS / 2);  // band-queue heads + abort flag
-    for (int l = 0; l + 1 < p->L; ++l) {
+    const int l_end = p->coarse_from > 0 ? p->coarse_from : p->L - 1;  // levels [0, l_end) are reduced level by level
+    for (int l = 0; l < l_end; ++l) {
         const Level& a = p->lv[l];
         const Level& b = p->lv[l + 1];
         const long lines = (long)np * a.h;
@@ -350,7 +355,11 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             mk.h = a.h;
             mk.enabled = 1;
         }
-        const bool wavefront = p->opts.blur_kind == 0 && do_x && do_y && l < p->wf_levels;
+        // The band pipeline pays where a launch has many bands in flight to hide its fill (see stitch_plan_create_batched): decided
+        // per CALL -- a batched plan asked for one pair runs the separate sweeps, which are faster for a lone pair (3.0 against
+        // 3.4 ms at 6144 x 4096) -- unless STITCH_WAVEFRONT or STITCH_SINGLE_FAST pins the form.
+        const bool wf_call = p->tune.wavefront >= 0 || p->tune.single_fast > 0 || n >= 2 || 7L * ((p->lv[0].h + TS - 1) / TS) >= 800;
+        const bool wavefront = p->opts.blur_kind == 0 && do_x && do_y && l < p->wf_levels && wf_call;
         // zero-tile flags: only where all three users run (causal x sweep, fused sweep, fused anticausal-y + decimation)
         const int NR = (a.h + TS - 1) / TS;  // 64-row bands per plane, the last one possibly partial
         ZeroTiles zt{};
@@ -480,6 +489,19 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             k_decimate<<<grid_xy(b.pitch, b.h, np), 256, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, b.g, b.w, b.h, b.pitch, b.ps, 0, 0);
         }
     }
+    if (p->coarse_from > 0) {  // every remaining level in one launch, one workgroup per pair; leaves E of level coarse_from
+        StageTimer t(p, s, STITCH_K_COARSE, p->coarse_from);
+        CoarseArgs ca{};
+        ca.n = p->L - p->coarse_from;
+        for (int i = 0; i < ca.n; ++i) {
+            const Level& v = p->lv[p->coarse_from + i];
+            ca.lv[i] = CoarseLevel{v.g, v.e, v.ix, v.iy, v.ax, v.ay, v.w, v.h, v.pitch, v.ps};
+        }
+        ca.T = p->T;
+        ca.k = p->vvk;
+        ca.dbg = p->co_dbg;
+        k_coarse<<<n, CO_THREADS, 0, s>>>(ca);
+    }
     if (p->wf_levels > 0) HIPCHK(hipMemcpyAsync(p->h_wf_abort, p->wf_ctrl + WF_CTRL_WORDS, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     return launch_check("reduce");
 }
@@ -493,13 +515,14 @@ int crows_of(const stitch_plan* p, int l) {
 template <typename OUT>
 int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s, const PairArgs<OUT>& pa, bool src) {
     const int L = p->L;
-    {
+    if (p->coarse_from == 0) {
         const Level& t = p->lv[L - 1];
         StageTimer tm(p, s, STITCH_K_COLLAPSE_TOP, L - 1);
         k_blend_top<<<grid_xy(t.pitch, t.h, n), 256, 0, s>>>(t.g, t.pitch, t.h, t.ps, t.e);
         if (L == 1) k_emit_top<OUT><<<grid_xy(t.w, t.h, n), 256, 0, s>>>(t.e, t.w, t.h, t.pitch, t.ps, outs);  // writes out_u8 too
     }
-    for (int l = L - 2; l >= 0; --l) {
+    // with k_coarse the chain arrives collapsed down to level coarse_from
+    for (int l = (p->coarse_from > 0 ? p->coarse_from - 1 : L - 2); l >= 0; --l) {
         const Level& a = p->lv[l];
         const Level& nx = p->lv[l + 1];
         StageTimer tm(p, s, l == 0 ? STITCH_K_COLLAPSE_L0 : STITCH_K_COLLAPSE, l);
@@ -564,6 +587,15 @@ int check_plan_call(stitch_plan* p, const void* a, const void* b, const void* ou
     return STITCH_OK;
 }
 
+// Source fusion trades bytes for instructions: the consumers of level 0 gather their samples (64 four-byte gathers per lane and
+// tile in the causal x sweep) instead of streaming planes.  A launch sequence over several pairs is bound by the bytes it moves
+// and gains (12 % at config 2); ONE pair in flight is bound by the length of its recurrence chains, its sweeps have a SIMD to
+// themselves, and the gathers land on the critical path: measured at 4421 x 2315 / 1081 x 527, materialised S1 2.14 / 0.81 ms,
+// source-fused 2.27 / 0.84 ms per pair.  So the form is chosen per CALL: source-fused for two pairs or more, materialised
+// (k_compose / k_load_canvases; the implicit mask stays) for a lone pair.  STITCH_SINGLE_FAST=1 pins the fused forms for
+// single pairs too (A/B runs, tests).
+bool src_fused_call(const stitch_plan* p, int n) { return n >= 2 || p->tune.single_fast > 0; }
+
 // The launch sequence of n pairs (or of one dense-canvas blend, pa.a_dense): S1, seam scan, REDUCE, collapse.
 template <typename PX>
 int run_pairs(stitch_plan* p, const PairArgs<PX>& pa, const OutPtrs<PX>& outs, int n, hipStream_t s, bool src) {
@@ -615,7 +647,7 @@ int dev_blend(stitch_plan* p, const PX* d_a, const PX* d_b, PX* d_out, void* str
     pa.a_dense = 1;
     OutPtrs<PX> outs{};
     outs.p[0] = d_out;
-    const bool src = p->src_fuse && (unsigned long long)p->cw * p->ch * sizeof(PX) < 0xfffffff0ULL;  // 32-bit byte offsets into a channel plane
+    const bool src = p->src_fuse && src_fused_call(p, 1) && (unsigned long long)p->cw * p->ch * sizeof(PX) < 0xfffffff0ULL;  // 32-bit byte offsets into a channel plane
     return run_pairs<PX>(p, pa, outs, 1, as_stream(stream), src);
 }
 
@@ -648,7 +680,7 @@ int dev_pairs(stitch_plan* p, const stitch_pair_desc* d, int n, void* stream) {
         pa.offx[i] = d[i].offx;
         pa.offy[i] = d[i].offy;
     }
-    bool src = p->src_fuse;
+    bool src = p->src_fuse && src_fused_call(p, n);
     for (int i = 0; i < n; ++i)  // 32-bit element indices and byte offsets into one channel plane
         src = src && (unsigned long long)d[i].fw * d[i].fh * sizeof(PX) < 0xfffffff0ULL && (unsigned long long)d[i].mw * d[i].mh * sizeof(PX) < 0xfffffff0ULL;
     return run_pairs<PX>(p, pa, outs, n, as_stream(stream), src);
@@ -1506,6 +1538,23 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         if (tn.collapse4 >= 0) p->collapse4 = tn.collapse4 != 0;
         p->src_fuse = p->mask_opt && !tn.no_src_fuse;  // STITCH_NO_SRC_FUSE: A/B and tests, keep S1 as its own kernel (k_compose)
     }
+    // coarse levels in one launch (k_coarse): from the first level l >= 1 whose sides are both at most STITCH_COARSE (default 40;
+    // 0 = never), when at least two levels qualify.  One workgroup -- one CU -- per pair: measured on the reference's 1081 x 527
+    // panorama, the levels from 33 x 16 down take 65 us in k_coarse against 124 us as 31 launches of their own (4.5 us of
+    // start-up each, 15 us for a collapse level), but 67 x 32 already costs more in one CU (the collapse's ~220 double-precision
+    // operations per pixel) than spread over the chip.  Van Vliet only.
+    {
+        const int thr = std::min(tn.coarse >= 0 ? tn.coarse : 40, CO_MAXSIDE);
+        int lc = 1;
+        while (lc < L && std::max(lw[lc], lh[lc]) > thr) ++lc;
+        if (thr > 0 && o.blur_kind == 0 && !p->blur_skip && lc <= L - 2 && L - lc <= CO_MAXL) p->coarse_from = lc;
+        if (p->coarse_from && std::getenv("STITCH_COARSE_STAMP") &&
+            (hipMalloc((void**)&p->co_dbg, sizeof(unsigned long long) * CO_MAXL * 8) != hipSuccess ||
+             hipMemset(p->co_dbg, 0, sizeof(unsigned long long) * CO_MAXL * 8) != hipSuccess)) {
+            (void)hipGetLastError();
+            p->co_dbg = nullptr;
+        }
+    }
     // the slack rows and pitch padding are read by partial tiles: give them defined (zero) contents once
     if (hipMemset(p->arena, 0, off) != hipSuccess || hipHostMalloc((void**)&p->h_seam, sizeof(SeamDev) * B) != hipSuccess) {
         stitch_plan_destroy(p);
@@ -1551,6 +1600,27 @@ void stitch_plan_destroy(stitch_plan* p) {
     if (p->arena) (void)hipFree(p->arena);
     if (p->h_seam) (void)hipHostFree(p->h_seam);
     if (p->h_wf_abort) (void)hipHostFree(p->h_wf_abort);
+    if (p->co_dbg) {
+        unsigned long long h[CO_MAXL * 8];
+        if (hipMemcpy(h, p->co_dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            // s_memtime counts at 100 MHz: 10 ns per tick
+            const int nl = p->L - p->coarse_from;
+            std::fprintf(stderr, "[k_coarse stamps, pair 0 of the last launch, us] levels %d..%d:", p->coarse_from, p->L - 1);
+            for (int i = 0; i + 1 < nl; ++i) {
+                const unsigned long long t0 = i == 0 ? h[0] : h[(i - 1) * 8 + 3];
+                std::fprintf(stderr, " | %dx%d x %.1f y %.1f dec %.1f", p->lv[p->coarse_from + i].w, p->lv[p->coarse_from + i].h, (h[i * 8 + 1] - t0) * 0.01,
+                             (h[i * 8 + 2] - h[i * 8 + 1]) * 0.01, (h[i * 8 + 3] - h[i * 8 + 2]) * 0.01);
+            }
+            std::fprintf(stderr, " | top %.1f | collapse", (h[(nl - 1) * 8 + 4] - h[(nl - 2) * 8 + 3]) * 0.01);
+            unsigned long long prev = h[(nl - 1) * 8 + 4];
+            for (int i = nl - 2; i >= 0; --i) {
+                std::fprintf(stderr, " %.1f", (h[i * 8 + 5] - prev) * 0.01);
+                prev = h[i * 8 + 5];
+            }
+            std::fprintf(stderr, " | total %.1f\n", (prev - h[0]) * 0.01);
+        }
+        (void)hipFree(p->co_dbg);
+    }
     if (p->wf_dbg) {
         const size_t nwg = (size_t)p->wf_max_wgs;
         std::vector<unsigned long long> hsum(nwg * 8);
@@ -1635,6 +1705,7 @@ int stitch_plan_clear_fault(stitch_plan* p) {
 }
 
 int stitch_plan_capacity(const stitch_plan* p) { return p ? p->cap : 0; }
+int stitch_plan_coarse_from(const stitch_plan* p) { return p ? p->coarse_from : 0; }
 int stitch_plan_fast_paths(const stitch_plan* p) {
     if (!p) return 0;
     int f = 0;
@@ -1645,6 +1716,7 @@ int stitch_plan_fast_paths(const stitch_plan* p) {
         !(p->tune.gate64 && p->lv[0].h % TS))
         f |= STITCH_FAST_ZERO_TILES;
     if (!p->no_fuse && p->opts.blur_kind == 0 && !p->blur_skip && p->L >= 2 && (p->lv[0].w & 1) == 0 && p->lv[0].h > 1) f |= STITCH_FAST_FUSED_DECIMATE;
+    if (p->coarse_from > 0) f |= STITCH_FAST_COARSE_LEVELS;
     return f;
 }
 int stitch_plan_fused_sweep_levels(const stitch_plan* p) { return p ? p->wf_levels : 0; }

@@ -31,7 +31,7 @@ def shard_range(n_items, rank, world):
 
 
 def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample=4, fused_sweep_levels=0, fused_decimate=True,
-                      source_fused=False, implicit_mask=False):
+                      source_fused=False, implicit_mask=False, coarse_from=0):
     """SURVEY.md 8(d) byte accounting for one pair: every distinct input array read once + every output array
     written once, pyramid planes f32.  Returns (per_kernel, stages): `stages` are the canonical totals S1..S3 the
     headline fraction uses (independent of how the kernels are fused); `per_kernel` gives each of THIS implementation's
@@ -41,7 +41,9 @@ def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample
       fused_sweep_levels  levels whose anticausal-x and causal-y sweeps are one kernel (k_vv_xbyf: one R + one W)
       source_fused     level 0 is never materialised: k_src_index writes one 4-byte index plane; the causal x sweep and the
                        level-0 collapse read the frames (through that plane) instead of six level-0 planes
-      implicit_mask    the level-0 mask plane is never read (a step function of x); the fused sweep still writes its blur"""
+      implicit_mask    the level-0 mask plane is never read (a step function of x); the fused sweep still writes its blur
+      coarse_from      > 0: levels coarse_from .. L-1 run in one launch (k_coarse): it reads G of level coarse_from, writes E of
+                       that level and G, E of the levels above it; the per-level kernels are credited the finer levels only"""
     n = [w * h for w, h in zip(level_w, level_h)]
     L = len(n)
     P = n[0]
@@ -52,7 +54,8 @@ def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample
     F = min(fused_sweep_levels, L - 1)
     m0 = 6 if implicit_mask else 7  # level-0 planes that exist as inputs of the blur
     x_fwd = x_fwd_src = x_bwd = y_fwd = y_bwd = xbyf = 0
-    for l in range(L - 1):
+    Lr = coarse_from if coarse_from > 0 else L - 1  # levels [0, Lr) are reduced / collapsed by per-level launches
+    for l in range(Lr):
         rd = 4 * n[l] * (m0 if l == 0 else 7)
         wr = 4 * n[l] * 7
         if l == 0 and source_fused:
@@ -65,7 +68,7 @@ def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample
             x_bwd += rd + (4 * n[l] * m0 if l == 0 else wr)
             y_fwd += wr + wr
         y_bwd += wr + (7 * 4 * n[l + 1] if fused_decimate else wr)
-    decimate = 0 if fused_decimate else sum(7 * 4 * (n[l] + n[l + 1]) for l in range(L - 1))
+    decimate = 0 if fused_decimate else sum(7 * 4 * (n[l] + n[l + 1]) for l in range(Lr))
     if L > 1:
         g0_in = (inputs + 4 * P) if source_fused else 4 * 6 * P
         collapse_l0 = g0_in + (0 if implicit_mask else 4 * P) + 4 * 9 * n[1] + 3 * P * bytes_per_sample
@@ -77,9 +80,10 @@ def algorithmic_bytes(frame_px_a, frame_px_b, level_w, level_h, bytes_per_sample
         "mask": 0 if implicit_mask else 4 * P,
         "vv_x_fwd": x_fwd, "vv_x_fwd_src": x_fwd_src, "vv_x_bwd": x_bwd, "vv_y_fwd": y_fwd, "vv_y_bwd": y_bwd, "vv_xbyf": xbyf,
         "decimate": decimate,
-        "collapse_top": 4 * 10 * n[L - 1],
-        "collapse": sum(4 * (10 * n[l] + 9 * n[l + 1]) for l in range(1, L - 1)),
+        "collapse_top": 0 if coarse_from > 0 else 4 * 10 * n[L - 1],
+        "collapse": sum(4 * (10 * n[l] + 9 * n[l + 1]) for l in range(1, Lr)),
         "collapse_l0": collapse_l0,
+        "coarse": 4 * 10 * sum(n[l] for l in range(coarse_from, L)) if coarse_from > 0 else 0,
     }
     return per_kernel, {"S1": s1, "S2": s2, "S3": s3, "total": s1 + s2 + s3}
 

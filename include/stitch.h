@@ -155,6 +155,8 @@ int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
  *   FUSED_SWEEP     anticausal-x and causal-y sweeps of the finest levels run as one kernel (stitch_plan_fused_sweep_levels)
  *   ZERO_TILES      all-zero 64x64 tiles of the blur scratch are flagged instead of stored (level 0; needs FUSED_SWEEP)
  *   FUSED_DECIMATE  level 0's anticausal y sweep writes the decimated level directly (even canvas widths)
+ *   COARSE_LEVELS   every level from the first one with both sides <= 40 on runs in ONE launch (k_coarse: REDUCE to the top,
+ *                   top blend, collapse back up; one workgroup per pair) instead of about six launches per level
  * IMPLICIT_MASK and SOURCE_FUSED hold for every canvas size with the Van Vliet blur (blur_kind 0, sigma >= 0.5) and at least
  * two pyramid levels. */
 enum {
@@ -162,9 +164,12 @@ enum {
     STITCH_FAST_SOURCE_FUSED = 2,
     STITCH_FAST_FUSED_SWEEP = 4,
     STITCH_FAST_ZERO_TILES = 8,
-    STITCH_FAST_FUSED_DECIMATE = 16
+    STITCH_FAST_FUSED_DECIMATE = 16,
+    STITCH_FAST_COARSE_LEVELS = 32
 };
 int stitch_plan_fast_paths(const stitch_plan *plan);
+/* First pyramid level of the COARSE_LEVELS launch (0 = none: every level has its own launch sequence). */
+int stitch_plan_coarse_from(const stitch_plan *plan);
 /* Tuning / A-B switches, read from the environment when a plan is created (none of them changes a result bit).  The
  * host-buffer entry points read them again on every call and key their workspace cache on the values, so a switch that
  * changes between two calls takes effect at once:
@@ -180,6 +185,11 @@ int stitch_plan_fast_paths(const stitch_plan *plan);
  *   STITCH_XBYF_SPIN_LIMIT=<n> polls before a hand-off wait of the fused sweep gives up (default 2^20; 0 forces the
  *                             bail-out path: tests of the sticky time-out report)
  *   STITCH_XBYF_EARLY=0       fused sweep: poll for the hand-off only when it is needed (default: read it ahead of the prefetch)
+ *   STITCH_COARSE=<n>         side length from which the coarse levels run in one launch (default 40; 0 = one launch sequence
+ *                             per level everywhere)
+ *   STITCH_SINGLE_FAST=1      one pair per call: run the throughput forms too (source-fused level 0, fused sweep on batched plans);
+ *                             default: a lone pair, whose time is the length of its recurrence chains, not its bytes, takes the
+ *                             materialised level 0 and the separate sweeps, which have the shorter chains
  *   STITCH_GATE64=1           implicit level-0 mask, source fusion and zero-tile flags only for level heights that are multiples
  *                             of 64 (the round-2 behaviour; A/B runs)
  *   STITCH_NO_FASTDIV=1       luminance mix: always the IEEE divide (default: reciprocal + fma correction where the host has
@@ -249,7 +259,8 @@ enum {
     STITCH_K_COLLAPSE_L0 = 10, /* k_collapse<T,true>: the same at level 0, writing the dense output canvas       */
     STITCH_K_VV_XBYF = 11,     /* k_vv_xbyf: anticausal-x + causal-y sweeps fused (row-band pipeline), finest levels */
     STITCH_K_VV_X_FWD_SRC = 12, /* k_vv_x_fwd<T,true>: the causal x sweep of a source-fused level 0 (reads the frames)  */
-    STITCH_K_COUNT = 13
+    STITCH_K_COARSE = 13,      /* k_coarse: all coarse levels in one launch (REDUCE, top blend, collapse)              */
+    STITCH_K_COUNT = 14
 };
 int stitch_plan_set_profiling(stitch_plan *plan, int enabled);
 /* Record events only around launches of one kernel id (near-zero overhead inside a timed region). */

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of builds of the same ABI inside ONE gpurun call (boxes differ by up to 8 %): scripts/ab_bench.sh <outdir> <lib|default>...
+# A/B of builds of the same ABI inside ONE gpurun call (boxes differ by up to 8 %): scripts/experiments/ab_bench.sh <outdir> <lib|default>...
 # each variant: bench.py --steps 10 --no-cpu-baseline with STITCH_LIB pointing at the build; one summary line per variant.
 out=$1; shift
 mkdir -p $out

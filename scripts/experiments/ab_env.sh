@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of run-time switches inside ONE gpurun call: scripts/ab_env.sh <outdir> "<name>:<ENV=VAL ...>" ...
+# A/B of run-time switches inside ONE gpurun call: scripts/experiments/ab_env.sh <outdir> "<name>:<ENV=VAL ...>" ...
 # each variant: bench.py --steps 10 --no-cpu-baseline with the given environment; one summary line per variant.
 out=$1; shift
 mkdir -p $out

@@ -1,7 +1,7 @@
 """N bands of one pair as N THREADS of one process (queues instead of torch.distributed): full BandStitcher.run, fused and
 plain anticausal sweep, two repetitions, against the oracle."""
 import os, sys, threading, queue
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np, torch
 from computervisionimagestich2_amd import pipeline
 from oracle_lib import Oracle

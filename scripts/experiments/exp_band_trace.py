@@ -1,6 +1,6 @@
 """The band code path as ONE band at config 5's size, a few repetitions (for rocprofv3 --kernel-trace)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from computervisionimagestich2_amd import capi, pipeline

@@ -1,7 +1,7 @@
 """Experiment: is the fused sweep bound by the band-to-band hand-off chain?  Same number of bands and tiles in one
 launch, but 64, 32 or 16 bands per plane (canvas heights 4096, 2048, 1024 with 4, 8, 16... planes' worth of pairs)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from computervisionimagestich2_amd import capi
 dev = torch.device("cuda:0")

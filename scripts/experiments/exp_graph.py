@@ -1,6 +1,6 @@
 """Experiment: time, status and output of every single replay / eager call in the order of exp_graph2."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from computervisionimagestich2_amd import capi, pipeline
 F = 4096; B = 3

@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from computervisionimagestich2_amd import capi
 dev = torch.device("cuda:0")
 out = []

@@ -1,7 +1,7 @@
 """One launch sequence of a batched plan, repeated (for rocprofv3 --kernel-trace: per-dispatch durations by kernel and grid).
-usage: python3 scripts/exp_seq.py [pairs=8] [reps=5] [frame=4096] [pixel=f32]"""
+usage: python3 scripts/experiments/exp_seq.py [pairs=8] [reps=5] [frame=4096] [pixel=f32]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from computervisionimagestich2_amd import capi, pipeline
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8

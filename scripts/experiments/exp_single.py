@@ -1,7 +1,7 @@
 """One single-pair plan at a given canvas, a few back-to-back calls (for rocprofv3 --kernel-trace timelines and quick timings).
-usage: python scripts/exp_single.py cw ch fw fh [reps] [pair|blend] [u8|f32]"""
+usage: python scripts/experiments/exp_single.py cw ch fw fh [reps] [pair|blend] [u8|f32]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from computervisionimagestich2_amd import capi

@@ -1,6 +1,6 @@
 """Experiment: S batched plans (B pairs each) in flight on S HIP streams."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from computervisionimagestich2_amd import capi, pipeline
 F = 4096

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""How the batches in flight overlap: from a rocprofv3 kernel trace of the bench (scripts/prof_lanes.sh), the time the
+"""How the batches in flight overlap: from a rocprofv3 kernel trace of the bench (scripts/experiments/prof_lanes.sh), the time the
 GPU spends with 0, 1, 2, ... kernels running, and for each kernel family the share of the wall time during which one of
 its launches is running and how much company it has on average."""
 import collections, csv, glob, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "lanes")
 f = sorted(glob.glob(os.path.join(src, "*", "*kernel_trace.csv")))[-1]
 rows = []

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace of the default four-lane bench (no stats, no per-launch events): input of scripts/lane_overlap.py
+# kernel trace of the default four-lane bench (no stats, no per-launch events): input of scripts/experiments/lane_overlap.py
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/lanes && mkdir -p gpurun_out/lanes

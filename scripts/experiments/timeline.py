@@ -1,7 +1,7 @@
 """Timeline of the LAST repetition of a launch sequence in a rocprofv3 --kernel-trace CSV: per dispatch its start (us from the
 sequence's first dispatch), duration and the idle gap since the previous dispatch ended.  The sequence starts at the last
 dispatch of <first-kernel-substring> (default k_seam ... the first kernel after S1).
-usage: python scripts/timeline.py <dir-or-csv> [first-kernel-substring]"""
+usage: python scripts/experiments/timeline.py <dir-or-csv> [first-kernel-substring]"""
 import csv, glob, os, sys
 p = sys.argv[1]
 first = sys.argv[2] if len(sys.argv) > 2 else "k_seam"

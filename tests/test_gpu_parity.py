@@ -172,6 +172,41 @@ def test_reference_canvas_sizes_take_the_fast_path(st, gpu, oracle, cw, ch, fw, 
     assert s.as_tuple() == rs.as_tuple() and np.array_equal(got.view(np.uint8), refb.view(np.uint8))
 
 
+@pytest.mark.parametrize("coarse", ["0", "24", "40", "146", "400"])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_coarse_levels_in_one_launch(st, gpu, oracle, dtype, coarse, monkeypatch):
+    """k_coarse: every pyramid level from the first one with both sides <= STITCH_COARSE on (default 40) runs in ONE launch,
+    one workgroup per pair -- REDUCE to the top, the top blend, the collapse back up -- instead of about six launches per
+    level.  Same bits as the per-level launches (STITCH_COARSE=0) and as the oracle: landscape and portrait canvases, odd
+    sizes (three-tap decimation rows / columns), a level of width 1 at the top, thresholds that give work-items one line
+    (146), several lines (400: the coarse launch starts at 292 x 131 / 200 x 350 / 350 x 175) or a few samples (24), batches."""
+    import torch
+    from computervisionimagestich2_amd import capi
+    monkeypatch.setenv("STITCH_COARSE", coarse)
+    for (cw, ch, n) in [(1081, 527, 1), (400, 700, 2), (585, 263, 3), (200, 350, 1), (1170, 600, 1)]:
+        plan = capi.Plan(cw, ch, max_pairs=n)
+        L = plan.levels
+        lw, lh = plan.level_w, plan.level_h
+        want = next((l for l in range(1, L) if max(lw[l], lh[l]) <= int(coarse)), L)
+        assert plan.coarse_from == (want if int(coarse) > 0 and want <= L - 2 else 0), (cw, ch, coarse, plan.coarse_from)
+        assert ("coarse_levels" in plan.fast_paths) == (plan.coarse_from > 0)
+        items, refs = [], []
+        for i in range(n):
+            fw, fh = max(40, cw * 2 // 3 - 7 * i), max(40, ch - 11 * i)
+            F, M = oracle.synth(fw, fh, 2 * i + 1, dtype), oracle.synth(cw - fw // 2, ch, 2 * i, dtype)
+            P = [1.0, 0.002, 1e-6, -(cw - fw - 2.0), -0.001, 1.0, 5e-7, 1.5 * i]
+            rc, ref = oracle.pair(F, P, 0.0, 0.0, M, 0, 0, cw, ch)
+            assert rc == 0, (cw, ch, i, rc)
+            refs.append(ref)
+            items.append((torch.from_numpy(F).to(gpu), P, 0.0, 0.0, torch.from_numpy(M).to(gpu), 0, 0,
+                          torch.empty((3, ch, cw), dtype=torch.uint8 if dtype == np.uint8 else torch.float32, device=gpu)))
+        outs = plan.pairs(items)
+        for i in range(n):
+            plan.status(i)
+            assert np.array_equal(outs[i].cpu().numpy().view(np.uint8), refs[i].view(np.uint8)), (cw, ch, coarse, i)
+        plan.close()
+
+
 def test_blend_errors(st, gpu, oracle):
     A, B = two_canvases(oracle, 128, 64, 1, 2, np.uint8)
     A0 = A.copy()
