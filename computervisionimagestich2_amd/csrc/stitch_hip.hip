@@ -190,7 +190,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp, gate64, coarse, single_fast;
+        recompute, stamp, gate64, coarse, single_fast, odd_dec;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -213,6 +213,7 @@ struct Tuning {
         t.gate64 = env_int("STITCH_GATE64") > 0;
         t.coarse = env_int("STITCH_COARSE");
         t.single_fast = env_int("STITCH_SINGLE_FAST");
+        t.odd_dec = env_int("STITCH_ODD_DEC");
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -375,6 +376,8 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
         if (mk.enabled || (src && l == 0) || zt.flags) bd = Bands{NR, a.h};
         const int nbx = bd.nr ? np * bd.nr : (int)((lines + TS - 1) / TS);
         const bool rowz = zt.flags && (a.h % YCH) != 0;  // fused anticausal-y + decimation: a chunk of rows may straddle bands
+        // odd widths decimate inside the anticausal sweep too (three overlaps per output column); a width of 1 has no next level column
+        const bool odd_dec = (a.w & 1) != 0 && a.w >= 3 && !p->no_fuse && p->tune.odd_dec != 0;
         if (wavefront) {
             const int nb = nbx;
             const bool rcmp = (p->recompute == 1 || (p->recompute == 2 && l >= 1)) && !(p->wf_dbg && l == 0);
@@ -438,6 +441,9 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 else
                     k_vv_y_bwd_dec<false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
                 decimated = true;
+            } else if (odd_dec) {  // odd width: three-tap x decimation, workgroups overlap by two columns
+                k_vv_y_bwd_dec<false, YST, false, true><<<dim3((b.w + WAVE - 2) / (WAVE - 1), np), 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
+                decimated = true;
             } else
                 k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, state_y, nullptr, nullptr);
         } else if (p->opts.blur_kind == 0) {
@@ -468,6 +474,9 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
                 if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
                     k_vv_y_bwd_dec<false, YST, false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
+                    decimated = true;
+                } else if (odd_dec) {
+                    k_vv_y_bwd_dec<false, YST, false, true><<<dim3((b.w + WAVE - 2) / (WAVE - 1), np), 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
                     decimated = true;
                 } else
                     k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, nullptr, nullptr);
@@ -507,7 +516,14 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
 }
 
 int crows_of(const stitch_plan* p, int l) {
-    if (l == 0) return p->crows_l0;
+    if (l == 0) {
+        // 32-row strips re-use the x-interpolated source rows best, but a strip is one serial chain of rows and a small canvas has
+        // few strips: 1081 x 527 in 32-row strips is 85 workgroups on 256 CUs (76 us); shorter strips where the launch would not fill
+        // the chip.  STITCH_CROWS_L0 pins the height.
+        if (p->tune.crows_l0 >= 0) return p->crows_l0;
+        const int h = p->lv[0].h;
+        return h >= 2048 ? p->crows_l0 : h >= 1024 ? 16 : 8;
+    }
     if (p->crows_ln > 0) return p->crows_ln;
     return std::max(4, std::min(4 * CROWS, p->lv[l].h / 32));
 }
@@ -530,17 +546,21 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
         // column per work-item on the rest, in ONE launch (k_collapse4); levels without such a range run k_collapse
         int xa = 0, xb = 0;
         if (p->collapse4) xa = a.c4_xa, xb = a.c4_xb;
+        int u8_words = 1;  // level 0: unsigned char rows start on 32-bit boundaries
         if (l == 0) {
-            bool ok = (a.w % 4) == 0;
-            for (int i = 0; i < n; ++i) ok = ok && (reinterpret_cast<uintptr_t>(outs.p[i]) % (4 * sizeof(OUT))) == 0 && (reinterpret_cast<uintptr_t>(outs.q[i]) % 4) == 0;
-            if (!ok) xa = xb = 0;
+            u8_words = (a.w % 4) == 0;
+            for (int i = 0; i < n; ++i) {
+                if (sizeof(OUT) == 1) u8_words = u8_words && (reinterpret_cast<uintptr_t>(outs.p[i]) % 4) == 0;
+                u8_words = u8_words && (reinterpret_cast<uintptr_t>(outs.q[i]) % 4) == 0;
+                if (sizeof(OUT) == 4 && (reinterpret_cast<uintptr_t>(outs.p[i]) % 4) != 0) xa = xb = 0;  // a float canvas that is not even 4-byte aligned
+            }
         }
         const int cols = l == 0 ? a.w : a.pitch, rest = cols - (xb - xa);
         const int nb4 = ((xb - xa) / 4 + WAVE - 1) / WAVE, ncb = (rest + C4_THREADS - 1) / C4_THREADS;
         if (l == 0) {  // level 0: the mask is the seam's step function itself (never read from memory)
             CollapseArgs<OUT, true> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, outs,
-                                      a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, p->crows_l0, xa, xb};
-            const int strips = (a.h + p->crows_l0 - 1) / p->crows_l0;
+                                      a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, crows_of(p, 0), xa, xb, u8_words};
+            const int strips = (a.h + A.crows - 1) / A.crows;
             if (xb > xa && src && pa.a_dense)
                 k_collapse4<OUT, true, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
             else if (xb > xa)
@@ -551,7 +571,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
             OutPtrs<float> eo{};
             eo.p[0] = a.e;
             CollapseArgs<float, false> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, eo,
-                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb};
+                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb, 1};
             const int strips = (a.h + A.crows - 1) / A.crows;
             if (xb > xa)
                 k_collapse4<float, false><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
@@ -1715,7 +1735,8 @@ int stitch_plan_fast_paths(const stitch_plan* p) {
     if (p->wf_levels > 0 && p->zero_tiles && !p->no_fuse && (p->lv[0].w & 1) == 0 && (p->lv[0].h + TS - 1) / TS <= 256 &&
         !(p->tune.gate64 && p->lv[0].h % TS))
         f |= STITCH_FAST_ZERO_TILES;
-    if (!p->no_fuse && p->opts.blur_kind == 0 && !p->blur_skip && p->L >= 2 && (p->lv[0].w & 1) == 0 && p->lv[0].h > 1) f |= STITCH_FAST_FUSED_DECIMATE;
+    if (!p->no_fuse && p->opts.blur_kind == 0 && !p->blur_skip && p->L >= 2 && ((p->lv[0].w & 1) == 0 || (p->lv[0].w >= 3 && p->tune.odd_dec != 0)) && p->lv[0].h > 1)
+        f |= STITCH_FAST_FUSED_DECIMATE;
     if (p->coarse_from > 0) f |= STITCH_FAST_COARSE_LEVELS;
     return f;
 }

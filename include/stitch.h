@@ -154,7 +154,7 @@ int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
  *                   (pairs: through an index plane of the warp; stitch_dev_blend_*: the dense canvases themselves)
  *   FUSED_SWEEP     anticausal-x and causal-y sweeps of the finest levels run as one kernel (stitch_plan_fused_sweep_levels)
  *   ZERO_TILES      all-zero 64x64 tiles of the blur scratch are flagged instead of stored (level 0; needs FUSED_SWEEP)
- *   FUSED_DECIMATE  level 0's anticausal y sweep writes the decimated level directly (even canvas widths)
+ *   FUSED_DECIMATE  level 0's anticausal y sweep writes the decimated level directly (any canvas width >= 2 rows high)
  *   COARSE_LEVELS   every level from the first one with both sides <= 40 on runs in ONE launch (k_coarse: REDUCE to the top,
  *                   top blend, collapse back up; one workgroup per pair) instead of about six launches per level
  * IMPLICIT_MASK and SOURCE_FUSED hold for every canvas size with the Van Vliet blur (blur_kind 0, sigma >= 0.5) and at least
@@ -187,6 +187,7 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *   STITCH_XBYF_EARLY=0       fused sweep: poll for the hand-off only when it is needed (default: read it ahead of the prefetch)
  *   STITCH_COARSE=<n>         side length from which the coarse levels run in one launch (default 40; 0 = one launch sequence
  *                             per level everywhere)
+ *   STITCH_ODD_DEC=0          odd level widths: anticausal y sweep and decimation as two kernels (default: fused, as for even widths)
  *   STITCH_SINGLE_FAST=1      one pair per call: run the throughput forms too (source-fused level 0, fused sweep on batched plans);
  *                             default: a lone pair, whose time is the length of its recurrence chains, not its bytes, takes the
  *                             materialised level 0 and the separate sweeps, which have the shorter chains
