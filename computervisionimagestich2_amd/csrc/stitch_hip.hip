@@ -614,7 +614,9 @@ int check_plan_call(stitch_plan* p, const void* a, const void* b, const void* ou
 // source-fused 2.27 / 0.84 ms per pair.  So the form is chosen per CALL: source-fused for two pairs or more, materialised
 // (k_compose / k_load_canvases; the implicit mask stays) for a lone pair.  STITCH_SINGLE_FAST=1 pins the fused forms for
 // single pairs too (A/B runs, tests).
-bool src_fused_call(const stitch_plan* p, int n) { return n >= 2 || p->tune.single_fast > 0; }
+// (A lone pair that is large enough to fill the chip by itself -- 7 planes x 64-row bands >= 800, the fused sweep's own criterion:
+// config 5's 24576 x 16384 -- is a throughput case too: 23.5 ms source-fused against 25.9 ms materialised.)
+bool src_fused_call(const stitch_plan* p, int n) { return n >= 2 || p->tune.single_fast > 0 || 7L * ((p->lv[0].h + TS - 1) / TS) >= 800; }
 
 // The launch sequence of n pairs (or of one dense-canvas blend, pa.a_dense): S1, seam scan, REDUCE, collapse.
 template <typename PX>

@@ -261,6 +261,63 @@ class RankTransport:
                 t.copy_(c)
 
 
+class LocalTransport:
+    """RankTransport's interface for ranks that are THREADS of one process driving ONE device, each on its own HIP stream (the
+    one-GPU form of the band split: tests, scripts/bench_band.py).  What crosses ranks never leaves the device and nobody waits
+    on the host for the GPU: a hand-off is a device copy made on the sender's stream plus an event; the receiving thread takes
+    the handle from a queue (a host-side hand-over of POINTERS, in enqueue order) and makes ITS stream wait for the event, so the
+    bands' kernels are ordered on the device exactly as RCCL's stream-ordered send / recv orders them across GPUs."""
+
+    def __init__(self, rank, world, queues):
+        self.rank, self.world, self.qs = rank, world, queues
+
+    @staticmethod
+    def make_queues(world):
+        import queue
+        return {(a, b): queue.Queue() for a in range(world) for b in range(world) if a != b}
+
+    def _post(self, t, dst):
+        import torch
+        c = t.clone()  # on this rank's stream: the source buffer may be rewritten by this rank's next launch
+        ev = torch.cuda.Event()
+        ev.record()
+        self.qs[(self.rank, dst)].put((c, ev))
+
+    def _take(self, src):
+        import torch
+        item = self.qs[(src, self.rank)].get()
+        if item is None:
+            raise RuntimeError(f"rank {src} failed")
+        c, ev = item
+        torch.cuda.current_stream().wait_event(ev)
+        c.record_stream(torch.cuda.current_stream())  # allocated on the sender's stream, consumed on this one
+        return c
+
+    def send(self, t, dst):
+        self._post(t, dst)
+
+    def recv(self, t, src):
+        t.copy_(self._take(src))
+        return t
+
+    def all_gather(self, t):
+        import torch
+        for d in range(self.world):
+            if d != self.rank:
+                self._post(t, d)
+        return torch.stack([t if s_ == self.rank else self._take(s_) for s_ in range(self.world)])
+
+    def swap(self, to_prev, to_next, from_prev, from_next):
+        if to_prev is not None:
+            self._post(to_prev, self.rank - 1)
+        if to_next is not None:
+            self._post(to_next, self.rank + 1)
+        if from_prev is not None:
+            from_prev.copy_(self._take(self.rank - 1))
+        if from_next is not None:
+            from_next.copy_(self._take(self.rank + 1))
+
+
 class BandStitcher:
     """One pair split into row bands over the ranks of a node (BASELINE.json configs[4]; SURVEY.md 8(e)(ii): recurrence
     state hand-off, not a transpose).  Every rank holds the input frames and calls run() with the same arguments; it gets

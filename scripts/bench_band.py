@@ -1,13 +1,12 @@
 """Config 5 (one 16384 x 16384 x 3 f32 pair -> 24576 x 16384 mosaic) on ONE MI355X: the ordinary single-GPU plan beside the
-band-split code path run as 1 band and as N bands on N streams of the same device (ranks as threads, queues for the
-exchange: tests/test_gpu_band.py's transport).  N bands on one GPU cannot be faster than one -- the point is what the split
+band-split code path run as 1 band and as N bands on N streams of the same device (ranks as threads; hand-offs on the device,
+pipeline.LocalTransport).  N bands on one GPU cannot be faster than one -- the point is what the split
 costs: the unfused sweeps, the per-plane hand-offs, the gather and the halos.  usage: bench_band.py [frame=16384] [split=4]"""
-import json, os, queue, sys, threading, time
+import json, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from computervisionimagestich2_amd import capi, pipeline
-from test_gpu_band import _QueueTransport
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 Ls = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 dev = torch.device("cuda:0")
@@ -29,14 +28,14 @@ res["plan_workspace_GB"] = round(plan.workspace_bytes / 1e9, 2)
 plan.close()
 ref = out
 for N in (1, 2, 8):
-    qs = {(a, b): queue.Queue() for a in range(N) for b in range(N) if a != b}
+    qs = pipeline.LocalTransport.make_queues(N)
     outs, times = [None] * N, [0.0] * N
     bar = threading.Barrier(N)
 
     def work(r):
         torch.cuda.set_device(0)
         with torch.cuda.stream(torch.cuda.Stream()):
-            bs = pipeline.BandStitcher(cw, ch, Ls, _QueueTransport(r, N, qs), dev)
+            bs = pipeline.BandStitcher(cw, ch, Ls, pipeline.LocalTransport(r, N, qs), dev)
             o = None
             for rep in range(3):
                 if rep == 1:

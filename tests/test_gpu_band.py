@@ -87,52 +87,13 @@ def test_single_rank_band_is_the_whole_pair(st, gpu, oracle):
     dist.destroy_process_group()
 
 
-class _QueueTransport:
-    """pipeline.RankTransport's interface over in-process queues: the ranks are THREADS of this process, each on its own HIP
-    stream (tests only: quick to start, and the bands' kernels really overlap on the device)."""
-
-    def __init__(self, rank, world, qs):
-        self.rank, self.world, self.qs = rank, world, qs
-
-    def _c(self, t):
-        import torch
-        c = t.clone()
-        torch.cuda.current_stream().synchronize()  # the receiver works on another stream
-        return c
-
-    def send(self, t, dst):
-        self.qs[(self.rank, dst)].put(self._c(t))
-
-    def recv(self, t, src):
-        t.copy_(self.qs[(src, self.rank)].get())
-        return t
-
-    def all_gather(self, t):
-        import torch
-        for d in range(self.world):
-            if d != self.rank:
-                self.qs[(self.rank, d)].put(self._c(t))
-        parts = [t if s_ == self.rank else self.qs[(s_, self.rank)].get() for s_ in range(self.world)]
-        return torch.stack(parts)
-
-    def swap(self, to_prev, to_next, from_prev, from_next):
-        if to_prev is not None:
-            self.qs[(self.rank, self.rank - 1)].put(self._c(to_prev))
-        if to_next is not None:
-            self.qs[(self.rank, self.rank + 1)].put(self._c(to_next))
-        if from_prev is not None:
-            from_prev.copy_(self.qs[(self.rank - 1, self.rank)].get())
-        if from_next is not None:
-            from_next.copy_(self.qs[(self.rank + 1, self.rank)].get())
-
-
 @pytest.mark.parametrize("world,fw,fh,cw,ch,Ls,dt", [(2, 1408, 1024, 2048, 1024, 3, "u8"), (3, 520, 384, 768, 384, 2, "u8"), (2, 520, 384, 770, 384, 2, "f32"),
                                                       (2, 1040, 768, 1540, 768, 2, "u8"), (6, 520, 384, 772, 384, 1, "f32"), (8, 1408, 1024, 2048, 1024, 2, "u8")])
 def test_pair_split_into_row_bands_threads(st, gpu, oracle, world, fw, fh, cw, ch, Ls, dt):
-    """The same split with the ranks as threads on separate HIP streams: more shapes (odd level widths -> the stand-alone
+    """The same split with the ranks as threads on separate HIP streams, handing over on the device (pipeline.LocalTransport:
+    a device copy and an event per hand-off, no host synchronisation): more shapes (odd level widths -> the stand-alone
     decimation, band counts that are not powers of two -> the level's, not the band's, decimation weights, 8 bands), two
     repetitions on the same workspaces."""
-    import queue
     import threading
     import torch
     from computervisionimagestich2_amd import pipeline
@@ -140,14 +101,14 @@ def test_pair_split_into_row_bands_threads(st, gpu, oracle, world, fw, fh, cw, c
     A, B, P = _inputs(oracle, fw, fh, dtype)
     rc, ref = oracle.pair(B, P, 0.0, 0.0, A, 0, 0, cw, ch)
     assert rc == 0
-    qs = {(a, b): queue.Queue() for a in range(world) for b in range(world) if a != b}
+    qs = pipeline.LocalTransport.make_queues(world)
     outs, errs = [[None, None] for _ in range(world)], []
 
     def work(r):
         try:
             torch.cuda.set_device(0)
             with torch.cuda.stream(torch.cuda.Stream()):
-                bs = pipeline.BandStitcher(cw, ch, Ls, _QueueTransport(r, world, qs), gpu)
+                bs = pipeline.BandStitcher(cw, ch, Ls, pipeline.LocalTransport(r, world, qs), gpu)
                 for rep in range(2):
                     outs[r][rep] = bs.run(torch.from_numpy(B).to(gpu), P, 0.0, 0.0, torch.from_numpy(A).to(gpu), 0, 0).cpu().numpy()
                 bs.close()
@@ -165,3 +126,74 @@ def test_pair_split_into_row_bands_threads(st, gpu, oracle, world, fw, fh, cw, c
         got = np.concatenate([outs[r][rep] for r in range(world)], axis=1)
         bad = np.argwhere(got != ref)
         assert bad.size == 0, (rep, len(bad), bad[:3].tolist())
+
+
+def test_config5_size_two_bands_equal_the_plan(st, gpu):
+    """BASELINE.json configs[4] at its full size through the band split: one 16384 x 16384 x 3 f32 pair -> 24576 x 16384 mosaic as
+    TWO row bands (ranks as threads on two streams of this GPU, device-side hand-offs) equals the single-GPU plan's mosaic bit for
+    bit -- and that plan is compared with the oracle at this size by test_config5_size_single_gpu_against_oracle."""
+    import threading
+    import torch
+    from computervisionimagestich2_amd import capi, pipeline
+    F, Ls, world = 16384, 4, 2
+    cw, ch = pipeline.config_canvas(F)
+    A, B = capi.dev_synth(F, F, 0, torch.float32, gpu), capi.dev_synth(F, F, 1, torch.float32, gpu)
+    p = pipeline.config_map(0, F)
+    plan = capi.Plan(cw, ch)
+    ref = plan.pair(B, p, 0.0, 0.0, A, 0, 0)
+    plan.status()
+    plan.close()
+    qs = pipeline.LocalTransport.make_queues(world)
+    outs, errs = [None] * world, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                bs = pipeline.BandStitcher(cw, ch, Ls, pipeline.LocalTransport(r, world, qs), gpu)
+                outs[r] = bs.run(B, p, 0.0, 0.0, A, 0, 0)
+                torch.cuda.current_stream().synchronize()
+                bs.close()
+        except Exception as e:
+            errs.append((r, repr(e)))
+            for k in qs:
+                if k[0] == r:
+                    qs[k].put(None)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=600) for t in th]
+    assert not errs, errs
+    assert torch.equal(torch.cat(outs, dim=1), ref)
+
+
+def test_rccl_transport_single_rank_smoke(st, gpu):
+    """pipeline.RankTransport(staged=False) -- the form a node runs: device tensors straight into RCCL -- with the one rank this
+    box has: all_gather and an (empty) neighbour exchange go through backend "nccl", and a one-band BandStitcher on top of it equals
+    the staged transport's result.  More ranks need more GPUs; the multi-rank logic is covered over gloo and by LocalTransport."""
+    import torch
+    import torch.distributed as dist
+    from computervisionimagestich2_amd import pipeline
+    from oracle_lib import Oracle
+    oracle = Oracle()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29541"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    try:
+        T = pipeline.RankTransport(staged=False)
+        t = torch.arange(24, dtype=torch.float32, device=gpu).reshape(2, 3, 4)
+        g = T.all_gather(t)
+        assert g.shape == (1, 2, 3, 4) and g.is_cuda and torch.equal(g[0], t)
+        T.swap(None, None, None, None)
+        fw, fh, cw, ch = 700, 500, 1000, 500
+        A, B, P = _inputs(oracle, fw, fh, np.float32)
+        bs = pipeline.BandStitcher(cw, ch, 2, T, gpu)
+        out = bs.run(torch.from_numpy(B).to(gpu), P, 0.0, 0.0, torch.from_numpy(A).to(gpu), 0, 0)
+        rc, ref = oracle.pair(B, P, 0.0, 0.0, A, 0, 0, cw, ch)
+        assert rc == 0 and np.array_equal(out.cpu().numpy().view(np.uint8), ref.view(np.uint8))
+        bs.close()
+    finally:
+        dist.destroy_process_group()
