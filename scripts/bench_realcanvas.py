@@ -1,8 +1,13 @@
 """The canvases the reference really builds (ImageProcess.cpp:206-216) are not multiples of 64: time one stitch step (pair)
-and one blendTwoImages (dense canvases) at 1081x527 and 4421x2315, device resident, single-pair plans, with the fast forms
-(implicit level-0 mask, source-fused level 0 at any height) and -- STITCH_GATE64=1 -- the round-2 materialised sequence, in one
-process on one box (the tuning switches are part of the plan, so both plans coexist).  Also config 3's whole chain.
-Usage: python scripts/bench_realcanvas.py > profiles/r03_real_canvases.json"""
+and one blendTwoImages (dense canvases) at 1081x527 and 4421x2315, device resident, in one process on one box (the tuning
+switches are part of a plan, so the variants coexist):
+  round2   the sequence round 2 ran at these sizes (STITCH_GATE64=1: materialised level 0 and mask; per-level launches down to
+           the top: STITCH_COARSE=0; odd widths decimated by a kernel of their own: STITCH_ODD_DEC=0; 32-row collapse strips)
+  default  what a call gets now: implicit mask, coarse levels in one launch, fused odd-width decimation, four-column level-0
+           collapse at any width; a lone pair keeps the materialised level 0 (shorter chains)
+  fused    STITCH_SINGLE_FAST=1: the throughput forms (source-fused level 0) for the lone pair too
+and a batch of 8 pairs per launch sequence, 4 sequences in flight, at 4421x2315 (round2 vs default: there the source-fused
+level 0 pays).  Also config 3's whole chain.  Usage: python scripts/bench_realcanvas.py > profiles/r03_real_canvases.json"""
 import hashlib
 import json
 import os
@@ -29,8 +34,18 @@ def timed(fn, n=30, warm=5):
     return (time.perf_counter() - t) / n * 1e3
 
 
-res = {"what": "ms per call, device resident, one pair in flight; gate64 = the round-2 sequence (materialised level 0 and mask "
-               "because the canvas height is not a multiple of 64)", "cases": []}
+VARIANTS = (("round2", {"STITCH_GATE64": "1", "STITCH_COARSE": "0", "STITCH_ODD_DEC": "0", "STITCH_CROWS_L0": "32"}), ("default", {}),
+            ("fused", {"STITCH_SINGLE_FAST": "1"}))
+SWITCHES = ("STITCH_GATE64", "STITCH_COARSE", "STITCH_ODD_DEC", "STITCH_CROWS_L0", "STITCH_SINGLE_FAST")
+
+
+def use(env):
+    for k in SWITCHES:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+
+
+res = {"what": "ms per call, device resident, one pair in flight unless stated", "cases": []}
 for (cw, ch, fw, fh) in [(1081, 527, 384, 512), (4421, 2315, 1536, 2048)]:
     for tdt, name in ((torch.uint8, "u8"), (torch.float32, "f32")):
         F, M = capi.dev_synth(fw, fh, 1, tdt, dev), capi.dev_synth(cw - fw // 2, ch - 7, 2, tdt, dev)
@@ -41,11 +56,8 @@ for (cw, ch, fw, fh) in [(1081, 527, 384, 512), (4421, 2315, 1536, 2048)]:
         capi.dev_move(M, 0, -2, B)
         row = {"canvas": [cw, ch], "frame": [fw, fh], "pixel": name}
         outs = {}
-        for label, gate in (("gate64", "1"), ("fast", None)):
-            if gate:
-                os.environ["STITCH_GATE64"] = gate
-            else:
-                os.environ.pop("STITCH_GATE64", None)
+        for label, env in VARIANTS:
+            use(env)
             plan = capi.Plan(cw, ch)
             out = torch.empty((3, ch, cw), dtype=tdt, device=dev)
             row[label + "_paths"] = sorted(plan.fast_paths)
@@ -56,22 +68,53 @@ for (cw, ch, fw, fh) in [(1081, 527, 384, 512), (4421, 2315, 1536, 2048)]:
             plan.status()
             outs[label] = (o1, out.clone())
             plan.close()
-        assert torch.equal(outs["gate64"][0], outs["fast"][0]) and torch.equal(outs["gate64"][1], outs["fast"][1])
-        assert torch.equal(outs["fast"][0], outs["fast"][1])  # the blend of the warped / moved canvases IS the pair
-        row["pair_speedup"] = round(row["gate64_pair_ms"] / row["fast_pair_ms"], 3)
-        row["blend_speedup"] = round(row["gate64_blend_ms"] / row["fast_blend_ms"], 3)
+        for label, _ in VARIANTS[1:]:
+            assert torch.equal(outs["round2"][0], outs[label][0]) and torch.equal(outs["round2"][1], outs[label][1])
+        assert torch.equal(outs["default"][0], outs["default"][1])  # the blend of the warped / moved canvases IS the pair
+        row["pair_speedup_default_vs_round2"] = round(row["round2_pair_ms"] / row["default_pair_ms"], 3)
+        row["blend_speedup_default_vs_round2"] = round(row["round2_blend_ms"] / row["default_blend_ms"], 3)
         res["cases"].append(row)
+
+# throughput at a real canvas size: 8 pairs per launch sequence, 4 sequences in flight (what a camera rig stitching frame
+# after frame with one geometry would run)
+cw, ch, fw, fh = 4421, 2315, 1536, 2048
+tdt = torch.float32
+F, M = capi.dev_synth(fw, fh, 1, tdt, dev), capi.dev_synth(cw - fw // 2, ch - 7, 2, tdt, dev)
+P = [1.0, 0.002, 1e-6, -(cw - fw - 3.0), -0.001, 1.0, 5e-7, -3.5]
+batch = {"canvas": [cw, ch], "pixel": "f32", "pairs_per_sequence": 8, "sequences_in_flight": 4}
+ref = None
+for label, env in VARIANTS[:2]:
+    use(env)
+    lanes = [(capi.Plan(cw, ch, max_pairs=8), torch.cuda.Stream(device=dev), [torch.empty((3, ch, cw), dtype=tdt, device=dev) for _ in range(8)]) for _ in range(4)]
+    batch[label + "_paths"] = sorted(lanes[0][0].fast_paths)
+
+    def go():
+        for plan, st, outs_ in lanes:
+            with torch.cuda.stream(st):
+                plan.pairs([(F, P, -0.25, -1.5, M, 0, -2, o) for o in outs_])
+
+    ms = timed(go, n=10, warm=3)
+    batch[label + "_ms_per_pair"] = round(ms / 32, 4)
+    batch[label + "_mpix_s"] = round(cw * ch / 1e6 / (ms / 32) * 1e3, 1)
+    for plan, st, outs_ in lanes:
+        plan.status(7)
+    if ref is None:
+        ref = lanes[0][2][0].clone()
+    assert all(torch.equal(o, ref) for _, _, outs_ in lanes for o in outs_)
+    for plan, _, _ in lanes:
+        plan.close()
+    del lanes
+    torch.cuda.empty_cache()
+batch["speedup_default_vs_round2"] = round(batch["round2_ms_per_pair"] / batch["default_ms_per_pair"], 3)
+res["batched_4421x2315"] = batch
 
 # config 3: the reference's own four frames, recorded stitch order, canvases 607x517 -> 838x522 -> 1081x527
 J = json.load(open(os.path.join(G, "golden.json")))
 frames = [torch.from_numpy(bmp.load_bmp(os.path.join(G, e["file"]))).to(dev) for e in J["input"]]
 steps = J["runs"]["4"]["steps"]
 chain = {"canvases": [[s["cw"], s["ch"]] for s in steps]}
-for label, gate in (("gate64", "1"), ("fast", None)):
-    if gate:
-        os.environ["STITCH_GATE64"] = gate
-    else:
-        os.environ.pop("STITCH_GATE64", None)
+for label, env in VARIANTS:
+    use(env)
     plans = {}
     chain[label + "_ms_per_panorama"] = round(timed(lambda: pipeline.stitch_chain(frames, steps, plans=plans), n=40), 4)
     out = pipeline.stitch_chain(frames, steps, plans=plans)

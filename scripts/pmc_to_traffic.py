@@ -27,11 +27,13 @@ GROUP = {"k_compose": "compose", "k_src_index": "compose", "k_seam": "seam", "k_
          "k_decimate": "decimate", "k_collapse<float, false>": "collapse", "k_collapse<float, true>": "collapse_l0",
          "k_collapse<unsigned char, true>": "collapse_l0", "k_collapse4<float, false>": "collapse", "k_collapse4<float, true>": "collapse_l0",
          "k_collapse4<unsigned char, true>": "collapse_l0", "k_blend_top": "collapse_top", "k_vv_xbyf<false>": "vv_xbyf",
-         "k_vv_xbyf<true>": "vv_xbyf"}
+         "k_vv_xbyf<true>": "vv_xbyf", "k_coarse": "coarse"}
 # template arguments added later (CKPT of the causal sweep, pixel type and MODE of the fused sweep) do not change the group
-GROUP_PREFIX = {"k_vv_x_fwd<float, true": "vv_x_fwd_src", "k_vv_x_fwd<unsigned char, true": "vv_x_fwd_src", "k_vv_x_fwd<": "vv_x_fwd", "k_vv_xbyf<": "vv_xbyf"}
-LAUNCH_GROUPS = {"compose": 1, "seam": 1, "mask": 1, "vv_x_fwd": 10, "vv_x_fwd_src": 1, "vv_x_bwd": 9, "vv_y_fwd": 9, "vv_y_bwd": 11, "decimate": 0,
-                 "collapse_top": 1, "collapse": 10, "collapse_l0": 1, "vv_xbyf": 2}  # config 2 with two fused-sweep levels
+GROUP_PREFIX = {"k_vv_x_fwd<float, true": "vv_x_fwd_src", "k_vv_x_fwd<unsigned char, true": "vv_x_fwd_src", "k_vv_x_fwd<": "vv_x_fwd", "k_vv_xbyf<": "vv_xbyf",
+                "k_collapse<float, false": "collapse", "k_collapse4<float, false": "collapse", "k_collapse<": "collapse_l0", "k_collapse4<": "collapse_l0"}
+# launches per launch sequence: config 2, two fused-sweep levels, levels 8..11 in k_coarse (round 3)
+LAUNCH_GROUPS = {"compose": 1, "seam": 1, "mask": 1, "vv_x_fwd": 7, "vv_x_fwd_src": 1, "vv_x_bwd": 6, "vv_y_fwd": 6, "vv_y_bwd": 8, "decimate": 0,
+                 "collapse_top": 0, "collapse": 7, "collapse_l0": 1, "vv_xbyf": 2, "coarse": 1}
 
 
 def kname(full):
