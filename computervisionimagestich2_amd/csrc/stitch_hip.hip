@@ -172,6 +172,19 @@ void regular_range(const std::vector<int32_t>& idx, int w, int sw, int sh, int* 
     if (best_b > best_a) *xa = best_a * 256, *xb = best_b * 256;
 }
 
+// The columns [0, *xb) (a multiple of 256) in which every group of four columns x0.. has its taps inside ONE 16-byte load at
+// ix[x0]: ix[x0 + 3] + 1 <= ix[x0] + 3 (always true for a step below 1/2) and ix[x0] + 3 inside the source row (see k_collapse4, GEN).
+void general_range(const std::vector<int32_t>& idx, int w, int sw, int sh, int* xb) {
+    *xb = 0;
+    if (sw < 4 || sh < 2) return;
+    int x0 = 0;
+    for (; x0 + 3 < w; x0 += 4) {
+        const int s_ = idx[x0];
+        if (!(idx[x0 + 1] >= s_ && idx[x0 + 2] >= idx[x0 + 1] && idx[x0 + 3] >= idx[x0 + 2] && idx[x0 + 3] - s_ <= 2 && s_ + 3 <= sw - 1)) break;
+    }
+    *xb = x0 / 256 * 256;
+}
+
 int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
     if (w <= 0 || h <= 0) return fail(STITCH_ERR_ARG, "pyramid: non-positive size %dx%d", w, h);
     const int len = level_rule ? (w < h ? w : h) : (w >= h ? w : h);
@@ -197,7 +210,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp, gate64, coarse, single_fast, odd_dec;
+        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -221,6 +234,7 @@ struct Tuning {
         t.coarse = env_int("STITCH_COARSE");
         t.single_fast = env_int("STITCH_SINGLE_FAST");
         t.odd_dec = env_int("STITCH_ODD_DEC");
+        t.c4_gen = env_int("STITCH_C4_GEN");
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -234,6 +248,7 @@ struct Level {
     int32_t *ix, *iy;  // expand tables level+1 -> level (levels < L-1)
     double *ax, *ay;
     int c4_xa, c4_xb;  // columns [c4_xa, c4_xb) of this level go to k_collapse4 (multiples of 256; empty when equal)
+    int c4_gen;        // != 0: [0, c4_xb) with per-lane tap offsets (k_collapse4 GEN) -- chosen where it covers more than the fixed pattern
 };
 
 constexpr int WF_CTRL_WORDS = 4 * 16 + 16;  // band-queue heads of up to 4 levels (64 bytes apart) + the abort word
@@ -568,10 +583,16 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
             CollapseArgs<OUT, true> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, outs,
                                       a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, crows_of(p, 0), xa, xb, u8_words};
             const int strips = (a.h + A.crows - 1) / A.crows;
-            if (xb > xa && src && pa.a_dense)
-                k_collapse4<OUT, true, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
+            const dim3 g4(nb4 + ncb * C4_SUB, strips, n);
+            const bool gen = a.c4_gen && p->collapse4;
+            if (xb > xa && src && pa.a_dense && gen)
+                k_collapse4<OUT, true, true, true><<<g4, C4_THREADS, 0, s>>>(A, nb4, ncb);
+            else if (xb > xa && src && pa.a_dense)
+                k_collapse4<OUT, true, true><<<g4, C4_THREADS, 0, s>>>(A, nb4, ncb);
+            else if (xb > xa && gen)
+                k_collapse4<OUT, true, false, true><<<g4, C4_THREADS, 0, s>>>(A, nb4, ncb);
             else if (xb > xa)
-                k_collapse4<OUT, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
+                k_collapse4<OUT, true><<<g4, C4_THREADS, 0, s>>>(A, nb4, ncb);
             else
                 k_collapse<OUT, true><<<grid_xy(cols, strips, n), 256, 0, s>>>(A);
         } else {
@@ -580,7 +601,9 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
             CollapseArgs<float, false> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, eo,
                                          a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb, 1};
             const int strips = (a.h + A.crows - 1) / A.crows;
-            if (xb > xa)
+            if (xb > xa && a.c4_gen && p->collapse4)
+                k_collapse4<float, false, false, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
+            else if (xb > xa)
                 k_collapse4<float, false><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
             else
                 k_collapse<float, false><<<grid_xy(cols, strips, n), 256, 0, s>>>(A);
@@ -1596,6 +1619,12 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         std::vector<double> al;
         expand_table(lw[l + 1], v.w, idx, al);
         regular_range(idx, v.w, lw[l + 1], lh[l + 1], &v.c4_xa, &v.c4_xb);
+        {
+            int gxb = 0;
+            general_range(idx, v.w, lw[l + 1], lh[l + 1], &gxb);
+            v.c4_gen = gxb >= (v.c4_xb - v.c4_xa) + 512 && tn.c4_gen != 0;  // worth the extra selects only where it gains two blocks or more
+            if (v.c4_gen) v.c4_xa = 0, v.c4_xb = gxb;
+        }
         (void)hipMemcpy(v.ix, idx.data(), sizeof(int32_t) * v.w, hipMemcpyHostToDevice);
         (void)hipMemcpy(v.ax, al.data(), sizeof(double) * v.w, hipMemcpyHostToDevice);
         expand_table(lh[l + 1], v.h, idx, al);
