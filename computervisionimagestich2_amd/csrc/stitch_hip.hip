@@ -210,7 +210,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen;
+        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -235,6 +235,7 @@ struct Tuning {
         t.single_fast = env_int("STITCH_SINGLE_FAST");
         t.odd_dec = env_int("STITCH_ODD_DEC");
         t.c4_gen = env_int("STITCH_C4_GEN");
+        t.collapse_px = env_int("STITCH_COLLAPSE_PX");
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -605,6 +606,8 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
                 k_collapse4<float, false, false, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
             else if (xb > xa)
                 k_collapse4<float, false><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
+            else if ((long)n * a.pitch * a.h <= 4096L * 64 * 2 && p->tune.collapse_px != 0)  // a launch that leaves most SIMDs with at most a wavefront or two
+                k_collapse_px<<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(A);
             else
                 k_collapse<float, false><<<grid_xy(cols, strips, n), 256, 0, s>>>(A);
         }

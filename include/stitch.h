@@ -187,6 +187,7 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *   STITCH_XBYF_EARLY=0       fused sweep: poll for the hand-off only when it is needed (default: read it ahead of the prefetch)
  *   STITCH_COARSE=<n>         side length from which the coarse levels run in one launch (default 40; 0 = one launch sequence
  *                             per level everywhere)
+ *   STITCH_COLLAPSE_PX=0      collapse of small middle levels in strips (k_collapse) instead of one pixel per work-item (k_collapse_px)
  *   STITCH_C4_GEN=0           collapse, odd level widths: four columns per work-item only where the resize taps follow the fixed pattern
  *                             (default: per-lane tap offsets wherever that covers two 256-column blocks more)
  *   STITCH_ODD_DEC=0          odd level widths: anticausal y sweep and decimation as two kernels (default: fused, as for even widths)
