@@ -196,8 +196,7 @@ def main():
     # launch sequence of G * n_local pairs -- steps run back to back without host synchronisation anyway, every step keeps its own
     # output buffers and its own gather -- so that a rank's launches are as long as the single-GPU run's (the fused sweep's fill
     # and the coarse levels' launches are paid once per sequence, not once per 4 pairs).  --no-coalesce: one sequence per step.
-    G = max(1, args.batch // n_local) if (nb == 1 and not args.no_coalesce) else 1
-    G = min(G, max(K, 1))
+    G = 1 if args.no_coalesce else pipeline.steps_per_sequence(n_local, args.batch, nb, K)
     S = max(1, min(args.streams, -(-nb * max(K, 1) // G)))
     pair_in = {}
     for i in range(lo, hi):
@@ -249,10 +248,7 @@ def main():
         shares per sequence.  The sequences are cut in step order (the gathers are submitted in step order on every rank) and
         balanced: their number is rounded up to a multiple of the lanes, so that the lanes finish together instead of one
         sequence running on alone at the end (20 steps, G = 4, 4 lanes: 3+3+3+3+2+2+2+2, not 4+4+4+4+4)."""
-        m = -(-count // G)
-        if G > 1 and m > S and m % S:
-            m = min(-(-m // S) * S, count)
-        sizes = [count // m + (1 if i < count % m else 0) for i in range(m)] if count > 0 else []
+        sizes = pipeline.sequence_sizes(count, G, S)
         k = k0
         for i, g in enumerate(sizes):
             steps_ = list(range(k, k + g))

@@ -95,6 +95,27 @@ def batches_of(n_pairs, rank, world, batch):
     return [(b, min(b + batch, hi)) for b in range(lo, hi, batch)]
 
 
+def steps_per_sequence(n_local, batch, n_seqs_per_step, steps):
+    """How many consecutive steps' shares a rank puts into ONE launch sequence: a shard smaller than a launch sequence (8 GPUs:
+    4 pairs per rank and step, sequences of up to 16) is launched together with the shares of the following steps -- steps run
+    back to back without host synchronisation anyway, every step keeps its own outputs and its own gather."""
+    if n_seqs_per_step != 1 or n_local <= 0:
+        return 1
+    return max(1, min(batch // n_local, max(steps, 1)))
+
+
+def sequence_sizes(count, per_seq, lanes):
+    """`count` steps cut, in step order, into launch sequences of at most `per_seq` steps each; when there are more sequences than
+    lanes their number is rounded up to a multiple of the lanes and the sizes are balanced, so that the lanes finish together
+    instead of one sequence running on alone at the end (20 steps, 4 per sequence, 4 lanes: 3+3+3+3+2+2+2+2, not 4+4+4+4+4)."""
+    if count <= 0:
+        return []
+    m = -(-count // per_seq)
+    if per_seq > 1 and m > lanes and m % lanes:
+        m = min(-(-m // lanes) * lanes, count)
+    return [count // m + (1 if i < count % m else 0) for i in range(m)]
+
+
 def stitch_chain(frames, steps, opts=None, finish=True, num=19.0, den=20.0, plans=None):
     """The hot-path calls of ImageProcess::matching for a recorded stitch order, device resident.
 

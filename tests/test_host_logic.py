@@ -52,6 +52,24 @@ def test_batches_of_is_the_config4_schedule():
     assert pipeline.batches_of(3, 3, 4, 8) == []
 
 
+def test_small_shares_are_launched_together():
+    """bench.py's schedule for a rank whose share of a step is smaller than a launch sequence (8 GPUs: 4 of 32 pairs)."""
+    assert pipeline.steps_per_sequence(4, 16, 1, 20) == 4    # 8 ranks: four steps' shares = 16 pairs per sequence
+    assert pipeline.steps_per_sequence(8, 16, 1, 20) == 2    # 4 ranks
+    assert pipeline.steps_per_sequence(16, 16, 1, 20) == 1   # 2 ranks: a share is a whole sequence
+    assert pipeline.steps_per_sequence(16, 16, 2, 20) == 1   # 1 rank: two sequences per step, nothing to merge
+    assert pipeline.steps_per_sequence(4, 16, 1, 3) == 3     # never more than the steps there are
+    assert pipeline.steps_per_sequence(5, 16, 1, 20) == 3    # ragged shard: 15 pairs per sequence
+    for count, g, lanes in [(20, 4, 4), (5, 4, 4), (3, 4, 4), (21, 4, 4), (20, 1, 4), (7, 2, 4), (1, 4, 4), (0, 4, 4), (64, 4, 3)]:
+        sizes = pipeline.sequence_sizes(count, g, lanes)
+        assert sum(sizes) == count and all(1 <= s_ <= g for s_ in sizes), (count, g, lanes, sizes)  # every step exactly once, in order
+        assert max(sizes, default=0) - min(sizes, default=0) <= 1
+        if g > 1 and len(sizes) > lanes:
+            assert len(sizes) % lanes == 0 or len(sizes) == count, (count, g, lanes, sizes)  # the lanes finish together
+    assert pipeline.sequence_sizes(20, 4, 4) == [3, 3, 3, 3, 2, 2, 2, 2]
+    assert pipeline.sequence_sizes(20, 1, 4) == [1] * 20
+
+
 def test_config_recipes():
     assert pipeline.config_canvas(4096) == (6144, 4096)
     assert pipeline.config_map(0) == [1.0, 0.002, 1e-6, -2048.0, -0.001, 1.0, 5e-7, 1.5]
