@@ -644,12 +644,19 @@ int check_plan_call(stitch_plan* p, const void* a, const void* b, const void* ou
 // tile in the causal x sweep) instead of streaming planes.  A launch sequence over several pairs is bound by the bytes it moves
 // and gains (12 % at config 2); ONE pair in flight is bound by the length of its recurrence chains, its sweeps have a SIMD to
 // themselves, and the gathers land on the critical path: measured at 4421 x 2315 / 1081 x 527, materialised S1 2.14 / 0.81 ms,
-// source-fused 2.27 / 0.84 ms per pair.  So the form is chosen per CALL: source-fused for two pairs or more, materialised
-// (k_compose / k_load_canvases; the implicit mask stays) for a lone pair.  STITCH_SINGLE_FAST=1 pins the fused forms for
-// single pairs too (A/B runs, tests).
+// source-fused 2.27 / 0.84 ms per pair.  So the form is chosen per CALL: source-fused for launch sequences with enough canvas
+// in them, materialised (k_compose / k_load_canvases; the implicit mask stays) otherwise.  STITCH_SINGLE_FAST=1 pins the fused
+// forms everywhere (A/B runs, tests).
+// Measured per launch sequence of n pairs, 1 and 4 sequences in flight (scripts/experiments/exp_srcfuse_n.py, ms per pair, fused /
+// materialised): 1081 x 527: n = 2 0.255 / 0.239, n = 8 0.053 / 0.047 (4 in flight), n = 16 0.040 / 0.046; 4421 x 2315: n = 2
+// 0.597 / 0.858 (4 in flight), n = 8 0.500 / 0.588.  The fused form pays from about 8 MPix of canvas per launch sequence.
 // (A lone pair that is large enough to fill the chip by itself -- 7 planes x 64-row bands >= 800, the fused sweep's own criterion:
 // config 5's 24576 x 16384 -- is a throughput case too: 23.5 ms source-fused against 25.9 ms materialised.)
-bool src_fused_call(const stitch_plan* p, int n) { return n >= 2 || p->tune.single_fast > 0 || 7L * ((p->lv[0].h + TS - 1) / TS) >= 800; }
+bool src_fused_call(const stitch_plan* p, int n) {
+    if (p->tune.single_fast > 0) return true;
+    if (7L * ((p->lv[0].h + TS - 1) / TS) >= 800) return true;
+    return n >= 2 && (long long)n * p->lv[0].w * p->lv[0].h >= 8000000LL;
+}
 
 // The launch sequence of n pairs (or of one dense-canvas blend, pa.a_dense): S1, seam scan, REDUCE, collapse.
 template <typename PX>

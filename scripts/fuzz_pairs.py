@@ -116,6 +116,7 @@ def _case(case, rng, O, capi, torch, dev, bad, done, verbose):
 if __name__ == "__main__":
     if os.environ.get("FUZZ_GENERAL") != "1":
         os.environ.setdefault("STITCH_WAVEFRONT", "2")
+        os.environ.setdefault("STITCH_SINGLE_FAST", "1")  # the throughput forms at these small canvases too
     done, bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 7, int(sys.argv[2]) if len(sys.argv) > 2 else 30)
     print(f"fuzz: {done} pairs compared bit for bit, {bad} mismatches, fused levels forced = {os.environ.get('STITCH_WAVEFRONT')}")
     sys.exit(1 if bad else 0)

@@ -79,6 +79,7 @@ def test_fused_sweep_many_bands_per_workgroup(st, gpu, oracle, monkeypatch, dtyp
     import torch
     from computervisionimagestich2_amd import capi
     monkeypatch.setenv("STITCH_WAVEFRONT", "2")
+    monkeypatch.setenv("STITCH_SINGLE_FAST", "1")  # the throughput forms at these small sizes too (the default picks them by canvas area per launch)
     monkeypatch.setenv("STITCH_XBYF_WGS", str(wgs))
     if recompute is not None:
         monkeypatch.setenv("STITCH_RECOMPUTE", str(recompute))

@@ -136,18 +136,20 @@ def test_pair(st, gpu, oracle, dtype):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("gate64", ["0", "1"])
+@pytest.mark.parametrize("gate64,single_fast", [("0", "0"), ("0", "1"), ("1", "0")])
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])
 @pytest.mark.parametrize("cw,ch,fw,fh", [(1081, 527, 384, 512), (607, 517, 384, 512), (838, 522, 384, 512), (1106, 579, 600, 500)])
-def test_reference_canvas_sizes_take_the_fast_path(st, gpu, oracle, cw, ch, fw, fh, dtype, gate64, monkeypatch):
+def test_reference_canvas_sizes_take_the_fast_path(st, gpu, oracle, cw, ch, fw, fh, dtype, gate64, single_fast, monkeypatch):
     """The canvases the reference builds (ImageProcess.cpp:206-216: ceil of warped corners -- 607x517, 838x522, 1081x527
     for its own Input/ frames; 4421x2315 is covered at a quarter of its size) are never multiples of 64: the implicit level-0
     mask and the source-fused level 0 run per-plane bands with a masked partial last band and hold for ANY canvas size,
-    for pairs and for stitch_blend_* (dense canvases read in place).  STITCH_GATE64=1 is the old materialised sequence:
-    same bits, and the oracle's."""
+    for pairs and for stitch_blend_* (dense canvases read in place).  A lone pair of this size takes the implicit mask but
+    keeps the materialised level 0 (shorter chains); STITCH_SINGLE_FAST=1 runs the source-fused forms (what a batch of such
+    canvases runs).  STITCH_GATE64=1 is the old materialised sequence: same bits, and the oracle's."""
     import torch
     from computervisionimagestich2_amd import capi
     monkeypatch.setenv("STITCH_GATE64", gate64)
+    monkeypatch.setenv("STITCH_SINGLE_FAST", single_fast)
     plan = capi.Plan(cw, ch)
     want = set() if gate64 == "1" else {"implicit_mask", "source_fused"}
     assert plan.fast_paths & {"implicit_mask", "source_fused"} == want, plan.fast_paths
@@ -371,6 +373,7 @@ def test_source_fused_level0_edge_cases(st, gpu, oracle, dtype, seam_rule, no_sr
     import torch
     from computervisionimagestich2_amd import capi
     monkeypatch.setenv("STITCH_NO_SRC_FUSE", no_src)
+    monkeypatch.setenv("STITCH_SINGLE_FAST", "1")  # the source-fused form at this small size too (by default chosen from 8 MPix per launch on)
     cw, ch = 832, 448
     opts = dict(sigma=2.0, blur_kind=0, level_rule=0, seam_rule=seam_rule)
     cases = [
@@ -503,6 +506,7 @@ def test_zero_tile_flags(st, gpu, oracle, no_zero_tiles, negative, cw, ch, monke
     import torch
     from computervisionimagestich2_amd import capi
     monkeypatch.setenv("STITCH_WAVEFRONT", "2")
+    monkeypatch.setenv("STITCH_SINGLE_FAST", "1")  # source-fused (index-tile flags) at this small size too
     monkeypatch.setenv("STITCH_NO_ZERO_TILES", no_zero_tiles)
     sy = ch / 512.0
     cases = [
@@ -543,6 +547,7 @@ def test_random_pairs_against_oracle(st, gpu, oracle, wavefront, seed, monkeypat
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     monkeypatch.setenv("STITCH_WAVEFRONT", wavefront)
+    monkeypatch.setenv("STITCH_SINGLE_FAST", "1")  # every fast path at these sizes (the default picks the forms by canvas area per launch)
     done, bad = fz.run(seed, 16)
     assert bad == 0 and done >= 4, (done, bad)  # the other cases ended in the same error code on both sides
 
