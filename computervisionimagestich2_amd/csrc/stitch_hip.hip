@@ -384,10 +384,12 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
         // 3.4 ms at 6144 x 4096) -- unless STITCH_WAVEFRONT or STITCH_SINGLE_FAST pins the form.
         const bool wf_call = p->tune.wavefront >= 0 || p->tune.single_fast > 0 || n >= 2 || 7L * ((p->lv[0].h + TS - 1) / TS) >= 800;
         const bool wavefront = p->opts.blur_kind == 0 && do_x && do_y && l < p->wf_levels && wf_call;
+        // odd widths decimate inside the anticausal sweep too (three overlaps per output column); a width of 1 has no next level column
+        const bool odd_dec = (a.w & 1) != 0 && a.w >= 3 && !p->no_fuse && p->tune.odd_dec != 0;
         // zero-tile flags: only where all three users run (causal x sweep, fused sweep, fused anticausal-y + decimation)
         const int NR = (a.h + TS - 1) / TS;  // 64-row bands per plane, the last one possibly partial
         ZeroTiles zt{};
-        if (wavefront && p->zero_tiles && NR <= 256 && (a.w & 1) == 0 && !p->no_fuse && !(p->tune.gate64 && a.h % TS)) {
+        if (wavefront && p->zero_tiles && NR <= 256 && ((a.w & 1) == 0 || odd_dec) && !p->no_fuse && !(p->tune.gate64 && (a.h % TS || (a.w & 1)))) {
             zt.flags = p->zt;
             zt.h = a.h;
             zt.NR = NR;
@@ -399,8 +401,6 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
         if (mk.enabled || (src && l == 0) || zt.flags) bd = Bands{NR, a.h};
         const int nbx = bd.nr ? np * bd.nr : (int)((lines + TS - 1) / TS);
         const bool rowz = zt.flags && (a.h % YCH) != 0;  // fused anticausal-y + decimation: a chunk of rows may straddle bands
-        // odd widths decimate inside the anticausal sweep too (three overlaps per output column); a width of 1 has no next level column
-        const bool odd_dec = (a.w & 1) != 0 && a.w >= 3 && !p->no_fuse && p->tune.odd_dec != 0;
         if (wavefront) {
             const int nb = nbx;
             const bool rcmp = (p->recompute == 1 || (p->recompute == 2 && l >= 1)) && !(p->wf_dbg && l == 0);
@@ -465,7 +465,11 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                     k_vv_y_bwd_dec<false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
                 decimated = true;
             } else if (odd_dec) {  // odd width: three-tap x decimation, workgroups overlap by two columns
-                k_vv_y_bwd_dec<false, YST, false, true><<<dim3((b.w + WAVE - 2) / (WAVE - 1), np), 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
+                const dim3 go((b.w + WAVE - 2) / (WAVE - 1), np);
+                if (rowz)
+                    k_vv_y_bwd_dec<true, YST, true, true><<<go, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
+                else
+                    k_vv_y_bwd_dec<false, YST, true, true><<<go, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, state_y, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
                 decimated = true;
             } else
                 k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, state_y, nullptr, nullptr);
@@ -1780,8 +1784,8 @@ int stitch_plan_fast_paths(const stitch_plan* p) {
     if (p->mask_opt) f |= STITCH_FAST_IMPLICIT_MASK;
     if (p->src_fuse) f |= STITCH_FAST_SOURCE_FUSED;
     if (p->wf_levels > 0) f |= STITCH_FAST_FUSED_SWEEP;
-    if (p->wf_levels > 0 && p->zero_tiles && !p->no_fuse && (p->lv[0].w & 1) == 0 && (p->lv[0].h + TS - 1) / TS <= 256 &&
-        !(p->tune.gate64 && p->lv[0].h % TS))
+    if (p->wf_levels > 0 && p->zero_tiles && !p->no_fuse && ((p->lv[0].w & 1) == 0 || (p->lv[0].w >= 3 && p->tune.odd_dec != 0)) &&
+        (p->lv[0].h + TS - 1) / TS <= 256 && !(p->tune.gate64 && (p->lv[0].h % TS || (p->lv[0].w & 1))))
         f |= STITCH_FAST_ZERO_TILES;
     if (!p->no_fuse && p->opts.blur_kind == 0 && !p->blur_skip && p->L >= 2 && ((p->lv[0].w & 1) == 0 || (p->lv[0].w >= 3 && p->tune.odd_dec != 0)) && p->lv[0].h > 1)
         f |= STITCH_FAST_FUSED_DECIMATE;
