@@ -365,8 +365,26 @@ class BandStitcher:
         self.band.close()
 
     def run(self, frame, p, offx, offy, mosaic, ox, oy, out=None):
+        """This rank's band of the mosaic.  Blocks only where the transport does (RCCL: nowhere on the host)."""
+        gen = self.steps(frame, p, offx, offy, mosaic, ox, oy, out)
+        T, val = self.t, None
+        try:
+            while True:
+                req = gen.send(val)
+                kind = req[0]
+                val = (T.send(*req[1:]) if kind == "send" else T.recv(*req[1:]) if kind == "recv" else
+                       T.all_gather(*req[1:]) if kind == "all_gather" else T.swap(*req[1:]))
+        except StopIteration as e:
+            out = e.value
+        self.seam = self.band.status()
+        return out
+
+    def steps(self, frame, p, offx, offy, mosaic, ox, oy, out=None):
+        """The band's launch sequence as a generator: it enqueues kernels and YIELDS what must cross ranks -- ("send", t, dst),
+        ("recv", t, src) -> t, ("all_gather", t) -> stacked, ("swap", to_prev, to_next, from_prev, from_next) -- so that one host
+        thread can interleave the sequences of several ranks (LocalBandGroup) and a rank of its own simply executes them (run)."""
         import torch
-        B, T, r, N, Ls = self.band, self.t, self.rank, self.world, self.Ls
+        B, r, N, Ls = self.band, self.rank, self.world, self.Ls
         g0 = self.geom[0]
         if out is None:
             out = torch.empty((3, g0["rows"], g0["w"]), dtype=frame.dtype, device=self.dev)
@@ -376,19 +394,20 @@ class BandStitcher:
             B.reduce_x(l)
             # causal sweep, rank 0 first; then the anticausal sweep + decimation, last rank first.  A band's sweep is one chain
             # of dependent rows -- as long for seven planes as for one -- so all planes go in one launch and one message
-            res = T.recv(self.res[l], r - 1) if r > 0 else None
+            res = (yield ("recv", self.res[l], r - 1)) if r > 0 else None
             B.reduce_y_fwd(l, -1, res, self.st_f[l])
             if r < N - 1:
-                T.send(self.st_f[l][:n3], r + 1)
-            res = T.recv(self.res[l], r + 1) if r < N - 1 else None
+                yield ("send", self.st_f[l][:n3], r + 1)
+            res = (yield ("recv", self.res[l], r + 1)) if r < N - 1 else None
             B.reduce_y_bwd(l, -1, self.st_f[l], res, self.st_b[l])
             if r > 0:
-                T.send(self.st_b[l], r - 1)
+                yield ("send", self.st_b[l], r - 1)
         # the first replicated level: gather the bands, run the coarse levels on every rank
         gt = self.geom[Ls]
         mine = torch.empty((7, gt["rows"], gt["w"]), dtype=torch.float32, device=self.dev)
         B.rows(Ls, 2, 0, gt["rows"], mine, True)
-        full = T.all_gather(mine).permute(1, 0, 2, 3).reshape(7, N * gt["rows"], gt["w"]).contiguous()
+        gathered = yield ("all_gather", mine)
+        full = gathered.permute(1, 0, 2, 3).reshape(7, N * gt["rows"], gt["w"]).contiguous()
         B.top(full)
         for l in range(Ls - 1, -1, -1):
             if l + 1 < Ls:  # halo rows of the level above: G (a, b) and E, from both neighbours
@@ -399,11 +418,143 @@ class BandStitcher:
                     first, last, above, below = mk(), mk(), mk(), mk()
                     B.rows(l + 1, kind, 0, H, first, True)
                     B.rows(l + 1, kind, rows - H, H, last, True)
-                    T.swap(first if r > 0 else None, last if r < N - 1 else None, above if r > 0 else None, below if r < N - 1 else None)
+                    yield ("swap", first if r > 0 else None, last if r < N - 1 else None, above if r > 0 else None, below if r < N - 1 else None)
                     if r > 0:
                         B.rows(l + 1, kind, -H, H, above, False)
                     if r < N - 1:
                         B.rows(l + 1, kind, rows, H, below, False)
             B.collapse(l, out if l == 0 else None)
-        self.seam = B.status()
         return out
+
+
+class _Addr:
+    """rank / world only: the BandStitchers of a LocalBandGroup never call a transport themselves."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+
+class LocalBandGroup:
+    """All N row bands of one pair on ONE device, driven by ONE host thread: every band has its own HIP stream, the bands'
+    launch sequences (BandStitcher.steps) are advanced round-robin, and what crosses bands is a device copy on the sender's stream
+    plus an event the receiver's stream waits for.  The host never waits for the GPU and never switches threads, so the device sees
+    the pure dependency graph of the split -- the one-GPU rehearsal of what RCCL's stream-ordered send / recv gives across GPUs
+    (8 bands at 24576 x 16384: 57 ms with host-staged hand-offs from 8 threads, 38.5 ms with device hand-offs from 8 threads,
+    this class: see profiles/r03_config5_band.json)."""
+
+    def __init__(self, cw, ch, split_levels, world, device, opts=None):
+        import collections
+        import torch
+        self.world, self.dev = world, device
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(world)]
+        self.bands = [BandStitcher(cw, ch, split_levels, _Addr(r, world), device, opts) for r in range(world)]
+        self.box = collections.defaultdict(collections.deque)  # (src, dst) -> posted (tensor, event), FIFO
+
+    def close(self):
+        for b in self.bands:
+            b.close()
+
+    def _post(self, t, src, dst):
+        import torch
+        c = t.clone()
+        ev = torch.cuda.Event()
+        ev.record()
+        self.box[(src, dst)].append((c, ev))
+
+    def _take(self, src, dst):
+        import torch
+        if not self.box[(src, dst)]:
+            return None
+        c, ev = self.box[(src, dst)].popleft()
+        torch.cuda.current_stream().wait_event(ev)
+        c.record_stream(torch.cuda.current_stream())
+        return c
+
+    def _try(self, r, st):
+        """Advance rank r's pending request as far as the posted messages allow; True when it is complete (st["val"] set)."""
+        import torch
+        req, N = st["req"], self.world
+        kind = req[0]
+        if kind == "send":
+            self._post(req[1], r, req[2])
+            st["val"] = None
+            return True
+        if kind == "recv":
+            c = self._take(req[2], r)
+            if c is None:
+                return False
+            req[1].copy_(c)
+            st["val"] = req[1]
+            return True
+        if kind == "all_gather":
+            if not st["posted"]:
+                for d in range(N):
+                    if d != r:
+                        self._post(req[1], r, d)
+                st["posted"], st["got"] = True, {r: req[1]}
+            for s_ in range(N):
+                if s_ not in st["got"]:
+                    c = self._take(s_, r)
+                    if c is None:
+                        return False
+                    st["got"][s_] = c
+            st["val"] = torch.stack([st["got"][s_] for s_ in range(N)])
+            return True
+        _, to_prev, to_next, from_prev, from_next = req  # swap
+        if not st["posted"]:
+            if to_prev is not None:
+                self._post(to_prev, r, r - 1)
+            if to_next is not None:
+                self._post(to_next, r, r + 1)
+            st["posted"], st["got"] = True, {}
+        for key, buf, src in (("p", from_prev, r - 1), ("n", from_next, r + 1)):
+            if buf is not None and key not in st["got"]:
+                c = self._take(src, r)
+                if c is None:
+                    return False
+                buf.copy_(c)
+                st["got"][key] = True
+        st["val"] = None
+        return True
+
+    def run(self, frame, p, offx, offy, mosaic, ox, oy, outs=None):
+        """-> the N bands of the mosaic (list, top to bottom)."""
+        import torch
+        N = self.world
+        ready = torch.cuda.Event()
+        ready.record()  # the inputs were produced on the caller's stream
+        gens = [b.steps(frame, p, offx, offy, mosaic, ox, oy, None if outs is None else outs[r]) for r, b in enumerate(self.bands)]
+        state = [{"req": None, "val": None, "posted": False, "got": None, "done": False, "out": None} for _ in range(N)]
+        for s_ in self.streams:
+            s_.wait_event(ready)
+        left = N
+        while left:
+            progressed = False
+            for r in range(N):
+                st = state[r]
+                if st["done"]:
+                    continue
+                with torch.cuda.stream(self.streams[r]):
+                    while True:
+                        if st["req"] is not None:
+                            if not self._try(r, st):
+                                break  # parked: the message has not been posted yet
+                            st["req"] = None
+                            progressed = True
+                        try:
+                            st["req"] = gens[r].send(st["val"])
+                            st["val"], st["posted"], st["got"] = None, False, None
+                        except StopIteration as e:
+                            st["done"], st["out"] = True, e.value
+                            left -= 1
+                            progressed = True
+                            break
+            if not progressed:
+                raise RuntimeError("band group: every rank waits for a message nobody has posted")
+        done = torch.cuda.Event()
+        for s_ in self.streams:  # the caller's stream continues behind every band
+            done.record(s_)
+            torch.cuda.current_stream().wait_event(done)
+        for b in self.bands:
+            b.seam = b.band.status()
+        return [st["out"] for st in state]

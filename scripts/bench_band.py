@@ -1,7 +1,7 @@
 """Config 5 (one 16384 x 16384 x 3 f32 pair -> 24576 x 16384 mosaic) on ONE MI355X: the ordinary single-GPU plan beside the
 band-split code path run as 1 band and as N bands on N streams of the same device (ranks as threads; hand-offs on the device,
 pipeline.LocalTransport).  N bands on one GPU cannot be faster than one -- the point is what the split
-costs: the unfused sweeps, the per-plane hand-offs, the gather and the halos.  usage: bench_band.py [frame=16384] [split=4]"""
+costs: the unfused sweeps, the hand-offs, the gather and the halos; LocalBandGroup = the same bands from one host thread.  usage: bench_band.py [frame=16384] [split=4]"""
 import json, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -55,5 +55,20 @@ for N in (1, 2, 8):
     res[f"band_path_{N}_band(s)_on_one_gpu_ms"] = round(max(times) * 1e3, 2)
     res[f"band_path_{N}_equals_plan"] = bool(torch.equal(got, ref))
     del outs, got
+    torch.cuda.empty_cache()
+# the same bands driven by ONE host thread (pipeline.LocalBandGroup): the device sees the pure dependency graph
+for N in (2, 8):
+    grp = pipeline.LocalBandGroup(cw, ch, Ls, N, dev)
+    outs = None
+    for rep in range(3):
+        if rep == 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        outs = grp.run(B, p, 0.0, 0.0, A, 0, 0, outs)
+    torch.cuda.synchronize()
+    res[f"band_group_{N}_bands_one_host_thread_ms"] = round((time.perf_counter() - t0) / 2 * 1e3, 2)
+    res[f"band_group_{N}_equals_plan"] = bool(torch.equal(torch.cat(outs, dim=1), ref))
+    grp.close()
+    del outs, grp
     torch.cuda.empty_cache()
 print(json.dumps(res, indent=1))
