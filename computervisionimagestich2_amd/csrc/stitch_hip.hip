@@ -825,7 +825,7 @@ int dev_project(const PX* d_src, int w, int h, float fov_deg, PX* d_dst, void* s
                 const long n_across = (long)std::ceil(vmax) - (long)std::floor(vmin) + 1, n_along = (long)std::ceil(u_of(ib)) - (long)std::floor(u_of(ia)) + 1;
                 const long rows = (pp.flag ? n_along : n_across) + 2;
                 const long cols = ((pp.flag ? n_across : n_along) + 2 * CPX + CPX - 1) / CPX * CPX;
-                lds = std::max(lds, (size_t)3 * rows * cols * sizeof(PX));
+                lds = std::max(lds, pj_box_bytes<PX>((size_t)rows * cols));
             }
         tiled = lds <= 60 * 1024;
     }
