@@ -242,6 +242,28 @@ def test_project_column_strip_kernel_equals_pixel_kernel(st, gpu, oracle, monkey
         assert np.array_equal(a[0], ref)
 
 
+def test_project_random_sizes_sweep(st, gpu, oracle):
+    """Seeded random frame sizes through every form of the projection: widths that are multiples of 4 (source box staged in
+    LDS: pixel-interleaved for unsigned char, planar for float; portrait and landscape kernels) and widths that are not (the
+    untiled kernel), tiles cut by the frame edge, frames smaller than one tile; fused gray planes included."""
+    rng = np.random.default_rng(20261005)
+    sizes = [(4 * int(rng.integers(1, 300)), int(rng.integers(1, 1300))) for _ in range(14)]
+    sizes += [(int(rng.integers(1, 1300)), 4 * int(rng.integers(1, 300))) for _ in range(6)]
+    sizes += [(int(rng.integers(1, 700)), int(rng.integers(1, 700))) for _ in range(6)]
+    sizes += [(128, 16), (128, 17), (132, 15), (256, 33), (64, 32), (68, 31), (2044, 50), (48, 2100)]
+    for i, (w, h) in enumerate(sizes):
+        fov = (15.0, 15.0, 30.0, 7.5)[i % 4]  # the reference's angle, a wider and a narrower cylinder
+        src = oracle.synth(w, h, 100 + i, np.uint8)
+        ref = oracle.project(src, fov)
+        dst, gray, gray_f32 = st.capi.project_gray(src, fov)
+        assert np.array_equal(dst, ref), (w, h, fov)
+        g, gf = oracle.gray(ref)
+        assert np.array_equal(gray, g) and np.array_equal(gray_f32, gf), (w, h, fov)
+        if i % 2 == 0:
+            srcf = oracle.synth(w, h, 200 + i, np.float32)
+            assert np.array_equal(st.capi.project(srcf, fov).view(np.uint32), oracle.project(srcf, fov).view(np.uint32)), (w, h, fov)
+
+
 @pytest.mark.parametrize("w,h", [(1081, 527), (300, 200), (64, 64), (7, 5), (2048, 1024)])
 def test_equalize_lummix_finish(st, gpu, oracle, w, h):
     img = oracle.synth(w, h, 11, np.uint8)
