@@ -609,6 +609,10 @@ class Band:
     def reduce_x(self, level):
         _chk(lib().stitch_band_reduce_x(self._h, int(level), _stream()))
 
+    def reduce_xy_fwd(self, level, resume, state_out):
+        """reduce_x + reduce_y_fwd(plane -1) with the anticausal x and causal y sweeps fused (one pass over the level)."""
+        _chk(lib().stitch_band_reduce_xy_fwd(self._h, int(level), _dp(resume) if resume is not None else None, _dp(state_out), _stream()))
+
     def reduce_y_fwd(self, level, plane, resume, state_out):
         _chk(lib().stitch_band_reduce_y_fwd(self._h, int(level), int(plane), _dp(resume) if resume is not None else None, _dp(state_out), _stream()))
 

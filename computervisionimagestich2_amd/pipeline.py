@@ -349,9 +349,14 @@ class BandStitcher:
       * the bands of the first replicated level are all-gathered and the coarse levels run on every rank;
       * before a split level is collapsed, two halo rows of G and E of the level above come from either neighbour."""
 
-    def __init__(self, cw, ch, split_levels, transport, device, opts=None):
+    def __init__(self, cw, ch, split_levels, transport, device, opts=None, fuse_sweeps=None):
         import torch
         self.t, self.dev = transport, device
+        # the anticausal x sweep fused with the causal y sweep (stitch_band_reduce_xy_fwd: one pass over a level less).  The fused
+        # sweep finds its parallelism in the 64-row bands of a plane, and a rank's share of the rows has few of them: at
+        # 24576 x 16384 one band gains (31.3 -> 29.6 ms) but two lose (31.1 -> 36.0) and eight take twice as long (40.6 -> 75.2 ms,
+        # profiles/r03_config5_band.json).  Default: only when there is no split.
+        self.fuse_sweeps = (transport.world == 1) if fuse_sweeps is None else bool(fuse_sweeps)
         self.rank, self.world = transport.rank, transport.world
         self.band = capi.Band(cw, ch, self.rank, self.world, split_levels, opts)
         self.Ls, self.geom = split_levels, self.band.geom
@@ -391,11 +396,15 @@ class BandStitcher:
         B.compose(frame, p, offx, offy, mosaic, ox, oy)
         for l in range(Ls):
             n3 = 3 * 7 * self.geom[l]["pitch"]
-            B.reduce_x(l)
+            if not self.fuse_sweeps:
+                B.reduce_x(l)
             # causal sweep, rank 0 first; then the anticausal sweep + decimation, last rank first.  A band's sweep is one chain
             # of dependent rows -- as long for seven planes as for one -- so all planes go in one launch and one message
             res = (yield ("recv", self.res[l], r - 1)) if r > 0 else None
-            B.reduce_y_fwd(l, -1, res, self.st_f[l])
+            if self.fuse_sweeps:
+                B.reduce_xy_fwd(l, res, self.st_f[l])
+            else:
+                B.reduce_y_fwd(l, -1, res, self.st_f[l])
             if r < N - 1:
                 yield ("send", self.st_f[l][:n3], r + 1)
             res = (yield ("recv", self.res[l], r + 1)) if r < N - 1 else None
@@ -442,12 +451,12 @@ class LocalBandGroup:
     (8 bands at 24576 x 16384: 57 ms with host-staged hand-offs from 8 threads, 38.5 ms with device hand-offs from 8 threads,
     this class: see profiles/r03_config5_band.json)."""
 
-    def __init__(self, cw, ch, split_levels, world, device, opts=None):
+    def __init__(self, cw, ch, split_levels, world, device, opts=None, fuse_sweeps=None):
         import collections
         import torch
         self.world, self.dev = world, device
         self.streams = [torch.cuda.Stream(device=device) for _ in range(world)]
-        self.bands = [BandStitcher(cw, ch, split_levels, _Addr(r, world), device, opts) for r in range(world)]
+        self.bands = [BandStitcher(cw, ch, split_levels, _Addr(r, world), device, opts, fuse_sweeps) for r in range(world)]
         self.box = collections.defaultdict(collections.deque)  # (src, dst) -> posted (tensor, event), FIFO
 
     def close(self):

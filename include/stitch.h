@@ -365,6 +365,9 @@ int stitch_band_compose_u8(stitch_band *band, const uint8_t *d_frame, int fw, in
 int stitch_band_compose_f32(stitch_band *band, const float *d_frame, int fw, int fh, const double p[8], float offx, float offy,
                             const float *d_mosaic, int mw, int mh, int ox, int oy, void *stream);
 int stitch_band_reduce_x(stitch_band *band, int level, void *stream);
+/* reduce_x + reduce_y_fwd(plane -1) with the anticausal x sweep and the causal y sweep fused into one pass over the level;
+ * resume: [3][7][pitch] from the rank above (NULL exactly on rank 0); state_out: [4][7][pitch] */
+int stitch_band_reduce_xy_fwd(stitch_band *band, int level, const double *d_resume, double *d_state_out, void *stream);
 /* resume: [3][pitch] doubles from the rank above (NULL exactly on rank 0); state_out: [4][pitch] doubles */
 int stitch_band_reduce_y_fwd(stitch_band *band, int level, int plane, const double *d_resume, double *d_state_out, void *stream);
 /* fwd_state: this plane's reduce_y_fwd state_out; resume: [3][pitch] from the rank below (NULL exactly on the last rank);

@@ -27,6 +27,8 @@ res["single_gpu_plan_ms"] = round((time.perf_counter() - t) / 3 * 1e3, 2)
 res["plan_workspace_GB"] = round(plan.workspace_bytes / 1e9, 2)
 plan.close()
 ref = out
+FUSE = {"1": True, "0": False}.get(os.environ.get("BAND_FUSE", ""), None)  # None: BandStitcher's default (fused only without a split)
+res["fused_sweeps"] = FUSE
 for N in (1, 2, 8):
     qs = pipeline.LocalTransport.make_queues(N)
     outs, times = [None] * N, [0.0] * N
@@ -35,7 +37,7 @@ for N in (1, 2, 8):
     def work(r):
         torch.cuda.set_device(0)
         with torch.cuda.stream(torch.cuda.Stream()):
-            bs = pipeline.BandStitcher(cw, ch, Ls, pipeline.LocalTransport(r, N, qs), dev)
+            bs = pipeline.BandStitcher(cw, ch, Ls, pipeline.LocalTransport(r, N, qs), dev, fuse_sweeps=FUSE)
             o = None
             for rep in range(3):
                 if rep == 1:
@@ -58,7 +60,7 @@ for N in (1, 2, 8):
     torch.cuda.empty_cache()
 # the same bands driven by ONE host thread (pipeline.LocalBandGroup): the device sees the pure dependency graph
 for N in (2, 8):
-    grp = pipeline.LocalBandGroup(cw, ch, Ls, N, dev)
+    grp = pipeline.LocalBandGroup(cw, ch, Ls, N, dev, fuse_sweeps=FUSE)
     outs = None
     for rep in range(3):
         if rep == 1:
