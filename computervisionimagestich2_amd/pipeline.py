@@ -339,6 +339,9 @@ class LocalTransport:
             from_next.copy_(self._take(self.rank + 1))
 
 
+PLANE_PIPELINE_MIN = None  # samples per plane of a band (rows x pitch) from which a level hands its state over plane by plane; None: never
+
+
 class BandStitcher:
     """One pair split into row bands over the ranks of a node (BASELINE.json configs[4]; SURVEY.md 8(e)(ii): recurrence
     state hand-off, not a transpose).  Every rank holds the input frames and calls run() with the same arguments; it gets
@@ -349,7 +352,7 @@ class BandStitcher:
       * the bands of the first replicated level are all-gathered and the coarse levels run on every rank;
       * before a split level is collapsed, two halo rows of G and E of the level above come from either neighbour."""
 
-    def __init__(self, cw, ch, split_levels, transport, device, opts=None, fuse_sweeps=None):
+    def __init__(self, cw, ch, split_levels, transport, device, opts=None, fuse_sweeps=None, plane_pipeline_min=None):
         import torch
         self.t, self.dev = transport, device
         # the anticausal x sweep fused with the causal y sweep (stitch_band_reduce_xy_fwd: one pass over a level less).  The fused
@@ -365,6 +368,17 @@ class BandStitcher:
         self.st_f = [torch.zeros(4 * 7 * g["pitch"], **f64) for g in self.geom[:-1]]  # causal state out (+ the band's last row)
         self.st_b = [torch.zeros(3 * 7 * g["pitch"], **f64) for g in self.geom[:-1]]  # anticausal state out
         self.res = [torch.zeros(3 * 7 * g["pitch"], **f64) for g in self.geom[:-1]]   # what a neighbour left
+        # Optional (plane_pipeline_min = samples per plane of a band from which a level does it): the state crosses ranks PLANE BY
+        # PLANE, so that rank r sweeps plane p while rank r+1 sweeps plane p-1 and the chain from rank to rank is 7 + N - 1
+        # plane-steps long instead of 7 N.  Off by default: a one-plane launch has 192-384 wavefronts and streams at a quarter of
+        # the seven-plane launch's rate, so on ONE GPU the split gets slower (24576 x 16384: 2 bands 31.4 -> 41.8 ms, 8 bands
+        # 38.7 -> 41.6 from one host thread), and what it would gain across 8 GPUs (a 14-step chain of slower steps) is not
+        # measurable on this pool.
+        pmin = PLANE_PIPELINE_MIN if plane_pipeline_min is None else plane_pipeline_min
+        self.per_plane = [pmin is not None and self.world > 1 and g["rows"] * g["pitch"] >= pmin for g in self.geom[:-1]]
+        self.st_fp = [torch.zeros((7, 4 * g["pitch"]), **f64) if pp else None for pp, g in zip(self.per_plane, self.geom[:-1])]
+        self.st_bp = [torch.zeros((7, 3 * g["pitch"]), **f64) if pp else None for pp, g in zip(self.per_plane, self.geom[:-1])]
+        self.res_p = [torch.zeros((7, 3 * g["pitch"]), **f64) if pp else None for pp, g in zip(self.per_plane, self.geom[:-1])]
 
     def close(self):
         self.band.close()
@@ -396,6 +410,20 @@ class BandStitcher:
         B.compose(frame, p, offx, offy, mosaic, ox, oy)
         for l in range(Ls):
             n3 = 3 * 7 * self.geom[l]["pitch"]
+            if self.per_plane[l]:
+                n1 = 3 * self.geom[l]["pitch"]
+                B.reduce_x(l)
+                for pl in range(7):
+                    res = (yield ("recv", self.res_p[l][pl], r - 1)) if r > 0 else None
+                    B.reduce_y_fwd(l, pl, res, self.st_fp[l][pl])
+                    if r < N - 1:
+                        yield ("send", self.st_fp[l][pl][:n1], r + 1)
+                for pl in range(7):
+                    res = (yield ("recv", self.res_p[l][pl], r + 1)) if r < N - 1 else None
+                    B.reduce_y_bwd(l, pl, self.st_fp[l][pl], res, self.st_bp[l][pl])
+                    if r > 0:
+                        yield ("send", self.st_bp[l][pl], r - 1)
+                continue
             if not self.fuse_sweeps:
                 B.reduce_x(l)
             # causal sweep, rank 0 first; then the anticausal sweep + decimation, last rank first.  A band's sweep is one chain
@@ -451,12 +479,12 @@ class LocalBandGroup:
     (8 bands at 24576 x 16384: 57 ms with host-staged hand-offs from 8 threads, 38.5 ms with device hand-offs from 8 threads,
     this class: see profiles/r03_config5_band.json)."""
 
-    def __init__(self, cw, ch, split_levels, world, device, opts=None, fuse_sweeps=None):
+    def __init__(self, cw, ch, split_levels, world, device, opts=None, fuse_sweeps=None, plane_pipeline_min=None):
         import collections
         import torch
         self.world, self.dev = world, device
         self.streams = [torch.cuda.Stream(device=device) for _ in range(world)]
-        self.bands = [BandStitcher(cw, ch, split_levels, _Addr(r, world), device, opts, fuse_sweeps) for r in range(world)]
+        self.bands = [BandStitcher(cw, ch, split_levels, _Addr(r, world), device, opts, fuse_sweeps, plane_pipeline_min) for r in range(world)]
         self.box = collections.defaultdict(collections.deque)  # (src, dst) -> posted (tensor, event), FIFO
 
     def close(self):

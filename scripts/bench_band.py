@@ -29,6 +29,8 @@ plan.close()
 ref = out
 FUSE = {"1": True, "0": False}.get(os.environ.get("BAND_FUSE", ""), None)  # None: BandStitcher's default (fused only without a split)
 res["fused_sweeps"] = FUSE
+PMIN = int(os.environ["BAND_PLANE_MIN"]) if "BAND_PLANE_MIN" in os.environ else None  # samples per plane from which hand-offs go plane by plane
+res["plane_pipeline_min"] = PMIN  # None: hand-offs per level (the default)
 for N in (1, 2, 8):
     qs = pipeline.LocalTransport.make_queues(N)
     outs, times = [None] * N, [0.0] * N
@@ -37,7 +39,7 @@ for N in (1, 2, 8):
     def work(r):
         torch.cuda.set_device(0)
         with torch.cuda.stream(torch.cuda.Stream()):
-            bs = pipeline.BandStitcher(cw, ch, Ls, pipeline.LocalTransport(r, N, qs), dev, fuse_sweeps=FUSE)
+            bs = pipeline.BandStitcher(cw, ch, Ls, pipeline.LocalTransport(r, N, qs), dev, fuse_sweeps=FUSE, plane_pipeline_min=PMIN)
             o = None
             for rep in range(3):
                 if rep == 1:
@@ -60,7 +62,7 @@ for N in (1, 2, 8):
     torch.cuda.empty_cache()
 # the same bands driven by ONE host thread (pipeline.LocalBandGroup): the device sees the pure dependency graph
 for N in (2, 8):
-    grp = pipeline.LocalBandGroup(cw, ch, Ls, N, dev, fuse_sweeps=FUSE)
+    grp = pipeline.LocalBandGroup(cw, ch, Ls, N, dev, fuse_sweeps=FUSE, plane_pipeline_min=PMIN)
     outs = None
     for rep in range(3):
         if rep == 1:
