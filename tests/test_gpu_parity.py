@@ -242,6 +242,17 @@ def test_project_column_strip_kernel_equals_pixel_kernel(st, gpu, oracle, monkey
         assert np.array_equal(a[0], ref)
 
 
+def test_project_degenerate_angles(st, gpu, oracle):
+    """Cylinder angles at which r is infinite, (almost) zero, negative or not a number: k leaves the range the tiled kernels'
+    hoisted-reciprocal quotient is exact for -- such frames never take those kernels (their source boxes exceed LDS, or the
+    box test fails) -- and the result must still be the reference's arithmetic, NaN comparisons included."""
+    for (w, h) in [(384, 512), (512, 384), (130, 77)]:
+        for fov in [0.0, 1e-3, 89.99, 90.0, 120.0, 180.0, -15.0, float("nan"), float("inf")]:
+            for dt in (np.uint8, np.float32):
+                src = oracle.synth(w, h, 3, dt)
+                assert np.array_equal(st.capi.project(src, fov).view(np.uint8), oracle.project(src, fov).view(np.uint8)), (w, h, fov, dt)
+
+
 def test_project_random_sizes_sweep(st, gpu, oracle):
     """Seeded random frame sizes through every form of the projection: widths that are multiples of 4 (source box staged in
     LDS: pixel-interleaved for unsigned char, planar for float; portrait and landscape kernels) and widths that are not (the
