@@ -433,7 +433,6 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             wf.mask_l0 = mk.enabled;
             wf.zt = zt;
             wf.early_read = p->wf_early_read;
-            wf.ph = a.h, wf.y0 = 0, wf.resume = nullptr;
             const long ntiles = (long)wf.NP * wf.NR;  // one persistent wavefront per row band
             // the x-sweep state lives in state[0 .. 4*lines); the y state the kernel leaves goes behind it
             double* state_y = p->state + 4 * (size_t)p->cap * 7 * (a.h + 64);
