@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from computervisionimagestich2_amd import capi
 dev = torch.device("cuda:0")
 out = []
-for (w, h, td) in [(4096, 4096, torch.uint8), (4096, 4096, torch.float32), (384, 512, torch.uint8)]:
+for (w, h, td) in [(4096, 4096, torch.uint8), (4096, 4096, torch.float32), (384, 512, torch.uint8)] + ([(4096, 3072, torch.uint8), (4096, 3072, torch.float32)] if os.environ.get("EXP_LANDSCAPE") else []):
     src = capi.dev_synth(w, h, 0, td, dev); dst = torch.empty_like(src)
     for _ in range(3): capi.dev_project(src, 15.0, dst)
     torch.cuda.synchronize(); a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); a.record()
