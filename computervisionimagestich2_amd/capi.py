@@ -606,6 +606,10 @@ class Band:
             self._h, _dp(frame), frame.shape[2], frame.shape[1], _map8(p), C.c_float(offx), C.c_float(offy), _dp(mosaic), mosaic.shape[2],
             mosaic.shape[1], int(ox), int(oy), _stream()))
 
+    def set_level0(self, source_fused):
+        """Level 0 source-fused (default) or materialised (what the one-plane-at-a-time sweeps need); before the next compose."""
+        _chk(lib().stitch_band_set_level0(self._h, int(bool(source_fused))))
+
     def reduce_x(self, level):
         _chk(lib().stitch_band_reduce_x(self._h, int(level), _stream()))
 

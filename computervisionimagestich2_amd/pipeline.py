@@ -376,6 +376,8 @@ class BandStitcher:
         # measurable on this pool.
         pmin = PLANE_PIPELINE_MIN if plane_pipeline_min is None else plane_pipeline_min
         self.per_plane = [pmin is not None and self.world > 1 and g["rows"] * g["pitch"] >= pmin for g in self.geom[:-1]]
+        if self.per_plane[0]:
+            self.band.set_level0(False)  # one plane at a time: level 0 must exist as planes
         self.st_fp = [torch.zeros((7, 4 * g["pitch"]), **f64) if pp else None for pp, g in zip(self.per_plane, self.geom[:-1])]
         self.st_bp = [torch.zeros((7, 3 * g["pitch"]), **f64) if pp else None for pp, g in zip(self.per_plane, self.geom[:-1])]
         self.res_p = [torch.zeros((7, 3 * g["pitch"]), **f64) if pp else None for pp, g in zip(self.per_plane, self.geom[:-1])]
@@ -424,12 +426,13 @@ class BandStitcher:
                     if r > 0:
                         yield ("send", self.st_bp[l][pl], r - 1)
                 continue
-            if not self.fuse_sweeps:
+            fuse = self.fuse_sweeps and l < 2  # as in a plan: the fused sweep on the two finest levels only (it loses on small levels)
+            if not fuse:
                 B.reduce_x(l)
             # causal sweep, rank 0 first; then the anticausal sweep + decimation, last rank first.  A band's sweep is one chain
             # of dependent rows -- as long for seven planes as for one -- so all planes go in one launch and one message
             res = (yield ("recv", self.res[l], r - 1)) if r > 0 else None
-            if self.fuse_sweeps:
+            if fuse:
                 B.reduce_xy_fwd(l, res, self.st_f[l])
             else:
                 B.reduce_y_fwd(l, -1, res, self.st_f[l])

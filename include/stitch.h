@@ -359,6 +359,10 @@ int stitch_band_create(int cw, int ch, int rank, int nranks, int split_levels, c
 void stitch_band_destroy(stitch_band *band);
 /* out[6] = {w, rows, row0, pitch, rows of the whole level, halo} of level 0..split_levels */
 int stitch_band_geometry(const stitch_band *band, int level, int out[6]);
+/* level 0 source-fused (1, the default: never stored, gathered from the frames; implicit mask) or materialised (0: needed by the
+ * one-plane-at-a-time forms of reduce_y_fwd / reduce_y_bwd); takes effect with the next compose.  STITCH_BAND_PLANES=1 in the
+ * environment at band creation selects 0. */
+int stitch_band_set_level0(stitch_band *band, int source_fused);
 int stitch_band_levels(const stitch_band *band, int *total_levels); /* returns split_levels */
 int stitch_band_compose_u8(stitch_band *band, const uint8_t *d_frame, int fw, int fh, const double p[8], float offx, float offy,
                            const uint8_t *d_mosaic, int mw, int mh, int ox, int oy, void *stream);

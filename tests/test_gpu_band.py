@@ -132,20 +132,24 @@ def test_pair_split_into_row_bands_threads(st, gpu, oracle, world, fw, fh, cw, c
 
 @pytest.mark.parametrize("world,fw,fh,cw,ch,Ls,dt", [(2, 1408, 1024, 2048, 1024, 3, "u8"), (3, 520, 384, 768, 384, 2, "f32"), (8, 1408, 1024, 2048, 1024, 2, "f32"),
                                                       (6, 520, 384, 772, 384, 1, "u8")])
-@pytest.mark.parametrize("fuse", [True, False, "planes"])
+@pytest.mark.parametrize("fuse", [True, False, "planes", "stored", "stored+fused"])
 def test_band_group_single_host_thread(st, gpu, oracle, world, fw, fh, cw, ch, Ls, dt, fuse):
     """pipeline.LocalBandGroup: all bands of a pair on one device, their launch sequences (BandStitcher.steps) interleaved by ONE
     host thread, hand-offs as device copies ordered by events -- the same generator a rank of its own executes over RCCL.  Two
     repetitions on the same workspaces; every band equals the oracle's rows.  fuse: the anticausal x sweep fused with the
     causal y sweep, which resumes from the state of the band above (stitch_band_reduce_xy_fwd), or the three separate sweeps, or
-    ("planes") the separate sweeps with the state handed from band to band plane by plane (the form large levels take)."""
+    ("planes") the separate sweeps with the state handed from band to band plane by plane (level 0 stored as planes).  Level 0 is
+    source-fused by default (index plane + gathers from the frames, implicit mask); "stored": the materialised level 0."""
     import torch
     from computervisionimagestich2_amd import pipeline
     dtype = np.uint8 if dt == "u8" else np.float32
     A, B, P = _inputs(oracle, fw, fh, dtype)
     rc, ref = oracle.pair(B, P, 0.0, 0.0, A, 0, 0, cw, ch)
     assert rc == 0
-    grp = pipeline.LocalBandGroup(cw, ch, Ls, world, gpu, fuse_sweeps=fuse is True, plane_pipeline_min=0 if fuse == "planes" else None)
+    grp = pipeline.LocalBandGroup(cw, ch, Ls, world, gpu, fuse_sweeps=fuse in (True, "stored+fused"), plane_pipeline_min=0 if fuse == "planes" else None)
+    if str(fuse).startswith("stored"):  # level 0 as seven stored planes (k_compose + k_mask) instead of source-fused
+        for b in grp.bands:
+            b.band.set_level0(False)
     dA, dB = torch.from_numpy(A).to(gpu), torch.from_numpy(B).to(gpu)
     for rep in range(2):
         outs = grp.run(dB, P, 0.0, 0.0, dA, 0, 0)
