@@ -355,10 +355,10 @@ class BandStitcher:
     def __init__(self, cw, ch, split_levels, transport, device, opts=None, fuse_sweeps=None, plane_pipeline_min=None):
         import torch
         self.t, self.dev = transport, device
-        # the anticausal x sweep fused with the causal y sweep (stitch_band_reduce_xy_fwd: one pass over a level less).  The fused
-        # sweep finds its parallelism in the 64-row bands of a plane, and a rank's share of the rows has few of them: at
-        # 24576 x 16384 one band gains (31.3 -> 29.6 ms) but two lose (31.1 -> 36.0) and eight take twice as long (40.6 -> 75.2 ms,
-        # profiles/r03_config5_band.json).  Default: only when there is no split.
+        # the anticausal x sweep fused with the causal y sweep on the two finest levels (stitch_band_reduce_xy_fwd: one pass over a
+        # level less).  The fused sweep finds its parallelism in the 64-row bands of a plane, and a rank's share of the rows has few
+        # of them: at 24576 x 16384 one band gains, two lose and eight take twice as long (profiles/r03_config5_band.json).
+        # Default: only when there is no split.
         self.fuse_sweeps = (transport.world == 1) if fuse_sweeps is None else bool(fuse_sweeps)
         self.rank, self.world = transport.rank, transport.world
         self.band = capi.Band(cw, ch, self.rank, self.world, split_levels, opts)

@@ -364,6 +364,9 @@ int stitch_band_geometry(const stitch_band *band, int level, int out[6]);
  * environment at band creation selects 0. */
 int stitch_band_set_level0(stitch_band *band, int source_fused);
 int stitch_band_levels(const stitch_band *band, int *total_levels); /* returns split_levels */
+/* compose: with the source-fused level 0 (the default) d_frame and d_mosaic are READ AGAIN by reduce_x / reduce_xy_fwd of level 0 and
+ * by collapse of level 0 -- they must stay valid and unchanged until that collapse has run (stream order is enough); the pixel type
+ * of that collapse's output must be the composed inputs'. */
 int stitch_band_compose_u8(stitch_band *band, const uint8_t *d_frame, int fw, int fh, const double p[8], float offx, float offy,
                            const uint8_t *d_mosaic, int mw, int mh, int ox, int oy, void *stream);
 int stitch_band_compose_f32(stitch_band *band, const float *d_frame, int fw, int fh, const double p[8], float offx, float offy,
