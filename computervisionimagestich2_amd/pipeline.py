@@ -450,7 +450,7 @@ class BandStitcher:
         full = gathered.permute(1, 0, 2, 3).reshape(7, N * gt["rows"], gt["w"]).contiguous()
         B.top(full)
         for l in range(Ls - 1, -1, -1):
-            if l + 1 < Ls:  # halo rows of the level above: G (a, b) and E, from both neighbours
+            if l + 1 < Ls and N > 1:  # halo rows of the level above: G (a, b) and E, from both neighbours (none without neighbours)
                 gs = self.geom[l + 1]
                 H, rows, w = gs["halo"], gs["rows"], gs["w"]
                 for kind, planes in ((0, 6), (1, 3)):
