@@ -160,6 +160,41 @@ def test_band_group_single_host_thread(st, gpu, oracle, world, fw, fh, cw, ch, L
     grp.close()
 
 
+def test_band_random_configs(st, gpu, oracle):
+    """Seeded random band splits against the oracle: 1-4 ranks, 1-3 split levels, even and odd canvas widths (odd widths keep the
+    separate anticausal sweep + decimation and no zero-tile flags), both pixel types, every form of the reduce (fused sweep with
+    and without neighbours, separate sweeps, stored level 0, plane-by-plane hand-off), frames that cover part of the canvas."""
+    import torch
+    from computervisionimagestich2_amd import pipeline
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_BANDS_SEED", "20261006")))
+    forms = [dict(fuse_sweeps=True), dict(fuse_sweeps=False), dict(fuse_sweeps=None), dict(fuse_sweeps=False, plane_pipeline_min=0), dict(fuse_sweeps=True, stored=True)]
+    for case in range(int(os.environ.get("FUZZ_BANDS", "30"))):  # FUZZ_BANDS=500 FUZZ_BANDS_SEED=n: a campaign
+        world, Ls = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        ch = world * (1 << Ls) * int(rng.integers(4, 14))
+        cw = int(rng.integers(260, 1300))
+        fw, fh = int(cw * rng.uniform(0.55, 0.8)), ch - int(rng.integers(0, 6))
+        dtype = np.uint8 if case % 2 else np.float32
+        form = dict(forms[case % len(forms)])
+        stored = form.pop("stored", False)
+        A, B = oracle.synth(fw, fh, 40 + case, dtype), oracle.synth(fw, fh, 80 + case, dtype)
+        P = [1.0, 0.002, 1e-6, -(cw - fw) + 3.0, -0.001, 1.0, 5e-7, 1.5]
+        rc, ref = oracle.pair(B, P, 0.0, 0.0, A, 0, 0, cw, ch)
+        if rc != 0:
+            continue
+        try:
+            grp = pipeline.LocalBandGroup(cw, ch, Ls, world, gpu, **form)
+        except st.capi.StitchError:
+            continue  # a pyramid too shallow for this split
+        if stored:
+            for b in grp.bands:
+                b.band.set_level0(False)
+        outs = grp.run(torch.from_numpy(B).to(gpu), P, 0.0, 0.0, torch.from_numpy(A).to(gpu), 0, 0)
+        got = torch.cat(outs, dim=1).cpu().numpy()
+        bad = np.argwhere(got.view(np.uint8) != ref.view(np.uint8))
+        assert bad.size == 0, (case, world, Ls, cw, ch, str(dtype), form, stored, len(bad), bad[:3].tolist())
+        grp.close()
+
+
 def test_config5_size_two_bands_equal_the_plan(st, gpu):
     """BASELINE.json configs[4] at its full size through the band split: one 16384 x 16384 x 3 f32 pair -> 24576 x 16384 mosaic as
     TWO row bands (ranks as threads on two streams of this GPU, device-side hand-offs) equals the single-GPU plan's mosaic bit for
