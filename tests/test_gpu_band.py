@@ -168,10 +168,13 @@ def test_band_random_configs(st, gpu, oracle):
     from computervisionimagestich2_amd import pipeline
     rng = np.random.default_rng(int(os.environ.get("FUZZ_BANDS_SEED", "20261006")))
     forms = [dict(fuse_sweeps=True), dict(fuse_sweeps=False), dict(fuse_sweeps=None), dict(fuse_sweeps=False, plane_pipeline_min=0), dict(fuse_sweeps=True, stored=True)]
-    for case in range(int(os.environ.get("FUZZ_BANDS", "30"))):  # FUZZ_BANDS=500 FUZZ_BANDS_SEED=n: a campaign
+    ran, skipped = 0, []
+    n_cases = int(os.environ.get("FUZZ_BANDS", "30"))  # FUZZ_BANDS=500 FUZZ_BANDS_SEED=n: a campaign
+    for case in range(n_cases):
         world, Ls = int(rng.integers(1, 5)), int(rng.integers(1, 4))
-        ch = world * (1 << Ls) * int(rng.integers(4, 14))
-        cw = int(rng.integers(260, 1300))
+        cw = int(rng.integers(200, 900))
+        base = world << Ls  # band heights even on every split level
+        ch = base * max(4, int(cw * rng.uniform(0.55, 1.1)) // base)  # tall enough for the pyramid the width asks for
         fw, fh = int(cw * rng.uniform(0.55, 0.8)), ch - int(rng.integers(0, 6))
         dtype = np.uint8 if case % 2 else np.float32
         form = dict(forms[case % len(forms)])
@@ -180,10 +183,12 @@ def test_band_random_configs(st, gpu, oracle):
         P = [1.0, 0.002, 1e-6, -(cw - fw) + 3.0, -0.001, 1.0, 5e-7, 1.5]
         rc, ref = oracle.pair(B, P, 0.0, 0.0, A, 0, 0, cw, ch)
         if rc != 0:
+            skipped.append((case, "oracle", rc))
             continue
         try:
             grp = pipeline.LocalBandGroup(cw, ch, Ls, world, gpu, **form)
-        except st.capi.StitchError:
+        except st.capi.StitchError as e:
+            skipped.append((case, world, Ls, cw, ch, str(e)[:80]))
             continue  # a pyramid too shallow for this split
         if stored:
             for b in grp.bands:
@@ -193,6 +198,9 @@ def test_band_random_configs(st, gpu, oracle):
         bad = np.argwhere(got.view(np.uint8) != ref.view(np.uint8))
         assert bad.size == 0, (case, world, Ls, cw, ch, str(dtype), form, stored, len(bad), bad[:3].tolist())
         grp.close()
+        ran += 1
+    print(f"band configs compared: {ran} of {n_cases}")
+    assert ran >= n_cases // 2, skipped[:6]
 
 
 def test_config5_size_two_bands_equal_the_plan(st, gpu):
