@@ -292,12 +292,62 @@ def test_equalize_lummix_finish(st, gpu, oracle, w, h):
     assert np.array_equal(st.lummix(img, got, 5.0, 6.0), oracle.lummix(img, ref, 5.0, 6.0))
 
 
+def test_host_entry_points_random_sequence(st, gpu, oracle, monkeypatch):
+    """The host-pointer entry points (what the C++ adaptor binds) take their workspaces from the plan cache: a seeded random
+    SEQUENCE of blends and stitch steps over a dozen canvas sizes (more than the cache holds: evictions and re-creations), both
+    pixel types, the ex6 options now and then, calls that must fail (an empty middle row, no overlap) in between, tuning switches
+    flipped between calls (part of the cache key) -- every output, seam and error code against the oracle."""
+    from oracle_lib import EX6_OPTS
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_HOST_SEED", "20261008")))
+    sizes = [(int(rng.integers(96, 700)), int(rng.integers(96, 520))) for _ in range(12)]
+    for call in range(int(os.environ.get("FUZZ_HOST", "40"))):
+        cw, ch = sizes[int(rng.integers(0, len(sizes)))]
+        dtype = np.uint8 if rng.random() < 0.6 else np.float32
+        opts = EX6_OPTS if rng.random() < 0.15 else None
+        for k in ("STITCH_NO_SRC_FUSE", "STITCH_COARSE", "STITCH_NO_ZERO_TILES"):
+            monkeypatch.delenv(k, raising=False)
+        flip = rng.random()
+        if flip < 0.15:
+            monkeypatch.setenv("STITCH_NO_SRC_FUSE", "1")
+        elif flip < 0.3:
+            monkeypatch.setenv("STITCH_COARSE", "0")
+        elif flip < 0.4:
+            monkeypatch.setenv("STITCH_NO_ZERO_TILES", "1")
+        if rng.random() < 0.5:  # blendTwoImages on two dense canvases
+            A, B = two_canvases(oracle, cw, ch, 3000 + call, 4000 + call, dtype, a_left=bool(rng.integers(0, 2)))
+            kind = rng.random()
+            if kind < 0.1:
+                A[0, ch // 2, :] = 0  # empty middle row of a
+            elif kind < 0.2:
+                B[:, :, :] = 0        # nothing of b on the middle row
+            rc, ref, seam = oracle.blend(A, B, opts) if opts is not None else oracle.blend(A, B)
+            try:
+                got, s_ = st.blend(A, B, opts) if opts is not None else st.blend(A, B)
+                assert rc == 0, (call, cw, ch, "oracle refused", rc)
+                assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)) and s_.as_tuple() == seam.as_tuple(), (call, "blend", cw, ch, str(dtype), flip)
+            except st.capi.StitchError as e:
+                assert rc != 0 and e.code == rc, (call, cw, ch, e.code, rc)
+        else:  # one stitch step: warp + move + blend
+            fw, fh = int(cw * rng.uniform(0.5, 0.8)), ch - int(rng.integers(0, 5))
+            F, M = oracle.synth(fw, fh, 1000 + call, dtype), oracle.synth(fw, fh, 2000 + call, dtype)
+            P = [1.0, float(rng.uniform(-0.004, 0.004)), float(rng.uniform(-2e-6, 2e-6)), -(cw - fw) + float(rng.uniform(0, 6)), float(rng.uniform(-0.002, 0.002)), 1.0,
+                 float(rng.uniform(-1e-6, 1e-6)), float(rng.uniform(-2, 2))]
+            offx, offy = float(np.float32(rng.uniform(-1, 1))), float(np.float32(rng.uniform(-1, 1)))
+            ox, oy = int(rng.integers(-3, 1)), int(rng.integers(-2, 3))
+            rc, ref = oracle.pair(F, P, offx, offy, M, ox, oy, cw, ch)
+            try:
+                got, s_ = st.pair(F, P, offx, offy, M, ox, oy, cw, ch)
+                assert rc == 0, (call, cw, ch, "oracle refused", rc)
+                assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (call, "pair", cw, ch, str(dtype), flip)
+            except st.capi.StitchError as e:
+                assert rc != 0 and e.code == rc, (call, cw, ch, e.code, rc)
+
+
 def test_other_rows_random_sizes(st, gpu, oracle):
     """Seeded random sizes through the rows around the blend (FUZZ_ROWS=n FUZZ_ROWS_SEED=s: a campaign): equalise + histogram, mix
     with random weights, fused finish, gray + SIFT staging, colour transfer with its twelve statistics, BMP encode / decode, warp and
     move with random offsets -- sizes of either parity and below one word (the byte forms of the four-pixels-per-word kernels),
     images with saturated and empty regions; every result against the oracle, bit for bit."""
-    import os
     from computervisionimagestich2_amd import capi
     rng = np.random.default_rng(int(os.environ.get("FUZZ_ROWS_SEED", "20261007")))
     for case in range(int(os.environ.get("FUZZ_ROWS", "24"))):
