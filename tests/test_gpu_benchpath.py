@@ -162,6 +162,8 @@ def test_batched_plans_random_pair_counts(st, gpu, oracle):
             cw, ch = 64 * int(rng.integers(4, 12)), 64 * int(rng.integers(3, 9))
         cap = int(rng.integers(1, 17))
         tdt, ndt = (torch.uint8, np.uint8) if case % 2 else (torch.float32, np.float32)
+        need = (1 << int(np.log2(max(cw, ch)))) // 2 + 1  # both sides long enough for the pyramid the longer side asks for
+        cw, ch = max(cw, need), max(ch, need)
         plan = capi.Plan(cw, ch, max_pairs=cap)
         for rep in range(2):
             n = cap if rep == 0 else int(rng.integers(1, cap + 1))
