@@ -273,6 +273,14 @@ def test_project_random_sizes_sweep(st, gpu, oracle):
         if i % 2 == 0:
             srcf = oracle.synth(w, h, 200 + i, np.float32)
             assert np.array_equal(st.capi.project(srcf, fov).view(np.uint32), oracle.project(srcf, fov).view(np.uint32)), (w, h, fov)
+        if i % 3 == 0:  # device buffers at odd byte offsets (the tiled kernels need 4-byte aligned planes: the untiled one takes over)
+            import torch
+            n, k = 3 * h * w, 1 + i % 3
+            buf_in, buf_out = torch.zeros(n + 8, dtype=torch.uint8, device=gpu), torch.zeros(n + 8, dtype=torch.uint8, device=gpu)
+            buf_in[k:k + n] = torch.from_numpy(src).to(gpu).flatten()
+            o = st.capi.dev_project(buf_in[k:k + n].view(3, h, w), fov, out=buf_out[3 - k:3 - k + n].view(3, h, w))
+            assert np.array_equal(o.cpu().numpy(), ref), (w, h, fov, "offset", k)
+            assert int(buf_out[:3 - k].sum()) == 0 and int(buf_out[3 - k + n:].sum()) == 0  # nothing written outside the image
 
 
 @pytest.mark.parametrize("w,h", [(1081, 527), (300, 200), (64, 64), (7, 5), (2048, 1024)])
