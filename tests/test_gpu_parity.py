@@ -351,6 +351,61 @@ def test_host_entry_points_random_sequence(st, gpu, oracle, monkeypatch):
                 assert rc != 0 and e.code == rc, (call, cw, ch, e.code, rc)
 
 
+def test_device_entry_points_at_odd_byte_offsets(st, gpu, oracle):
+    """The device-resident entry points on unsigned char tensors that start 1-3 bytes into an allocation (the four-pixels-per-word
+    forms of equalise / mix / finish / quantise, the word stores of the level-0 collapse, the tiled projection and the BMP kernels
+    all have an alignment condition and a byte form behind it): results equal the oracle's and the guard bytes either side of
+    every output stay untouched.  Plane sizes that are and are not multiples of 4."""
+    import torch
+    from computervisionimagestich2_amd import capi
+
+    def view_at(arr, k, fill=0):
+        """arr's bytes on the device starting k bytes into a buffer that is guarded by 8 bytes of `fill` either side"""
+        n = arr.size
+        buf = torch.full((n + 16,), fill, dtype=torch.uint8, device=gpu)
+        buf[8 + k:8 + k + n] = torch.from_numpy(arr).to(gpu).flatten()
+        return buf, buf[8 + k:8 + k + n].view(*arr.shape)
+
+    def guards_intact(buf, k, n, fill):
+        return bool((buf[:8 + k] == fill).all()) and bool((buf[8 + k + n:] == fill).all())
+
+    for (w, h) in [(128, 96), (127, 93), (260, 64), (66, 33)]:
+        img = oracle.synth(w, h, 31, np.uint8)
+        img[1] = np.maximum(img[1], 180)
+        ref, rhist, _ = oracle.equalize(img)
+        mixed = oracle.lummix(img, ref)
+        for k in (1, 2, 3):
+            buf, v = view_at(img, k, 0xA5)
+            hist = torch.zeros(256, dtype=torch.int32, device=gpu)
+            capi.dev_equalize(v, hist)
+            assert np.array_equal(v.cpu().numpy(), ref) and np.array_equal(hist.cpu().numpy(), rhist) and guards_intact(buf, k, img.size, 0xA5), ("equalize", w, h, k)
+            buf2, v2 = view_at(img, (k + 1) % 4, 0x5A)
+            capi.dev_lummix(v2, v)
+            assert np.array_equal(v2.cpu().numpy(), mixed) and guards_intact(buf2, (k + 1) % 4, img.size, 0x5A), ("lummix", w, h, k)
+            buf3, v3 = view_at(img, k, 0x3C)
+            capi.dev_finish(v3)
+            assert np.array_equal(v3.cpu().numpy(), mixed) and guards_intact(buf3, k, img.size, 0x3C), ("finish", w, h, k)
+            f32 = oracle.synth(w, h, 5, np.float32)
+            bufq, vq = view_at(np.zeros((3, h, w), np.uint8), k, 0x77)
+            capi.dev_quantize(torch.from_numpy(f32).to(gpu), out=vq)
+            assert np.array_equal(vq.cpu().numpy(), f32.astype(np.uint8)) and guards_intact(bufq, k, img.size, 0x77), ("quantize", w, h, k)
+    # one stitch step whose output (and inputs) sit at odd offsets: the level-0 collapse stores words only into aligned rows
+    for (cw, ch, k) in [(256, 192, 1), (260, 160, 3), (255, 131, 2)]:
+        fw, fh = int(cw * 0.7), ch - 2
+        F, M = oracle.synth(fw, fh, 61, np.uint8), oracle.synth(fw, fh, 62, np.uint8)
+        P = small_map(cw - fw - 4)
+        rc, ref = oracle.pair(F, P, 0.25, -0.5, M, 0, 1, cw, ch)
+        assert rc == 0
+        _, dF = view_at(F, k)
+        _, dM = view_at(M, (k + 2) % 4)
+        bufo, out = view_at(np.zeros((3, ch, cw), np.uint8), k, 0xC3)
+        plan = capi.Plan(cw, ch)
+        plan.pair(dF, P, 0.25, -0.5, dM, 0, 1, out=out)
+        plan.status()
+        assert np.array_equal(out.cpu().numpy(), ref) and guards_intact(bufo, k, 3 * ch * cw, 0xC3), ("pair", cw, ch, k)
+        plan.close()
+
+
 def test_other_rows_random_sizes(st, gpu, oracle):
     """Seeded random sizes through the rows around the blend (FUZZ_ROWS=n FUZZ_ROWS_SEED=s: a campaign): equalise + histogram, mix
     with random weights, fused finish, gray + SIFT staging, colour transfer with its twelve statistics, BMP encode / decode, warp and
