@@ -171,7 +171,7 @@ def test_band_random_configs(st, gpu, oracle):
     ran, skipped = 0, []
     n_cases = int(os.environ.get("FUZZ_BANDS", "30"))  # FUZZ_BANDS=500 FUZZ_BANDS_SEED=n: a campaign
     for case in range(n_cases):
-        world, Ls = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        world, Ls = int(rng.integers(1, int(os.environ.get("FUZZ_BANDS_WORLD", "4")) + 1)), int(rng.integers(1, 4))
         cw = int(rng.integers(200, 900))
         base = world << Ls  # band heights even on every split level
         ch = base * max(4, int(cw * rng.uniform(0.55, 1.1)) // base)  # tall enough for the pyramid the width asks for
