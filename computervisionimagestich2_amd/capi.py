@@ -19,7 +19,7 @@ KERNELS = ("compose", "seam", "mask", "vv_x_fwd", "vv_x_bwd", "vv_y_fwd", "vv_y_
            "collapse_l0", "vv_xbyf", "vv_x_fwd_src", "coarse")
 KERNEL_SYMBOLS = {"compose": "k_src_index (source-fused) / k_compose", "seam": "k_seam", "mask": "k_mask", "vv_x_fwd": "k_vv_x_fwd<T, false, false>", "vv_x_bwd": "k_vv_x_bwd",
                   "vv_y_fwd": "k_vv_y_fwd1 / k_vv_y_fwd", "vv_y_bwd": "k_vv_y_bwd_dec", "decimate": "k_decimate", "collapse_top": "k_blend_top",
-                  "collapse": "k_collapse<float, false>", "collapse_l0": "k_collapse<T, true>", "vv_xbyf": "k_vv_xbyf<false, float, 0>", "vv_x_fwd_src": "k_vv_x_fwd<T, true, false>",
+                  "collapse": "k_collapse<float, false>", "collapse_l0": "k_collapse<T, true>", "vv_xbyf": "k_vv_xbyf<false, float, 0, false>", "vv_x_fwd_src": "k_vv_x_fwd<T, true, false>",
                   "coarse": "k_coarse"}
 
 
