@@ -842,3 +842,59 @@ def test_host_entry_points_from_two_threads(st, gpu, oracle):
     [t.start() for t in th]
     [t.join(timeout=120) for t in th]
     assert not errs, errs
+
+
+def test_host_entry_points_from_six_threads_mixed(st, gpu, oracle):
+    """Six host threads at once, each running its own seeded mix of host-pointer calls -- blends and stitch steps on a handful
+    of canvas sizes shared between the threads (they compete for the same cached workspaces), projections, equalisations,
+    warps -- against results the oracle computed beforehand; stitch_trim() is called by one thread in the middle of it."""
+    import threading
+    from computervisionimagestich2_amd import capi
+    sizes = [(320, 240), (500, 300), (333, 257), (640, 384)]
+    jobs = {}
+    for i, (w, h) in enumerate(sizes):
+        for dt in (np.uint8, np.float32):
+            A, B = two_canvases(oracle, w, h, 11 + i, 21 + i, dt)
+            rc, ref, _ = oracle.blend(A, B)
+            assert rc == 0
+            jobs[("blend", i, dt)] = (A, B, ref)
+        fw, fh = int(w * 0.7), h - 3
+        F, M = oracle.synth(fw, fh, 31 + i, np.uint8), oracle.synth(fw, fh, 41 + i, np.uint8)
+        P = small_map(w - fw - 4)
+        rc, ref = oracle.pair(F, P, 0.5, -0.25, M, 0, 1, w, h)
+        assert rc == 0
+        jobs[("pair", i)] = (F, P, M, w, h, ref)
+        img = oracle.synth(w, h, 51 + i, np.uint8)
+        jobs[("project", i)] = (img, oracle.project(img))
+        jobs[("equalize", i)] = (img, oracle.equalize(img)[0])
+    keys = sorted(jobs.keys(), key=str)
+    errs = []
+
+    def work(tid):
+        rng = np.random.default_rng(100 + tid)
+        try:
+            for n in range(30):
+                k = keys[int(rng.integers(0, len(keys)))]
+                j = jobs[k]
+                if k[0] == "blend":
+                    got, _ = st.blend(j[0], j[1])
+                    ok = np.array_equal(got.view(np.uint8), j[2].view(np.uint8))
+                elif k[0] == "pair":
+                    got, _ = st.pair(j[0], j[1], 0.5, -0.25, j[2], 0, 1, j[3], j[4])
+                    ok = np.array_equal(got, j[5])
+                elif k[0] == "project":
+                    ok = np.array_equal(st.project(j[0]), j[1])
+                else:
+                    ok = np.array_equal(st.equalize(j[0])[0], j[1])
+                if not ok:
+                    errs.append(("mismatch", tid, n, str(k)))
+                if tid == 0 and n == 15:
+                    capi.trim()
+        except Exception as e:  # noqa: BLE001
+            errs.append((tid, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not any(t.is_alive() for t in th), "a thread is stuck"
+    assert not errs, errs[:5]
