@@ -210,7 +210,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px;
+        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, dec5, c4_lock, c4_swz;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -236,6 +236,10 @@ struct Tuning {
         t.odd_dec = env_int("STITCH_ODD_DEC");
         t.c4_gen = env_int("STITCH_C4_GEN");
         t.collapse_px = env_int("STITCH_COLLAPSE_PX");
+        t.y1s = env_int("STITCH_Y1S");
+        t.dec5 = env_int("STITCH_DEC5");
+        t.c4_lock = env_int("STITCH_C4_LOCKSTEP");
+        t.c4_swz = env_int("STITCH_C4_SWIZZLE");
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -491,19 +495,33 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * np, hipMemcpyDeviceToDevice, s));
             if (do_y) {
                 dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
+                // fewer than 1.5 wavefronts per SIMD: the launch's time is one wavefront's chain of rows, i.e. its instructions per
+                // row (k_sweeps1.inc): one column per work-item, rows through scalar offsets, the decimation on three consumer wavefronts
+                const bool lone = (long)g.x * g.y < 1536 && !p->tune.y2, small_plane = a.ps * sizeof(float) < 0x7fffffffULL;
                 {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
-                    if ((long)g.x * g.y < 1536 && !p->tune.y2)  // fewer than 1.5 wavefronts per SIMD: one column per work-item
+                    if (lone && small_plane && p->tune.y1s != 0 && (p->tune.y1s >= 2 || l >= 1 || a.ps * 7 * sizeof(float) * 2 < (200u << 20)))
+                        // (a level-0 sweep that moves more than the chip's caches hold is bound by bytes and streams better on flat addresses)
+                        k_vv_y_fwd1s<<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
+                    else if (lone)
                         k_vv_y_fwd1<<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
                     else
                         k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
                 }
                 StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
+                const bool dec5 = lone && small_plane && p->tune.dec5 != 0;
                 if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
-                    k_vv_y_bwd_dec<false, YST, false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
+                    if (dec5)
+                        k_vv_y_bwd_dec5<false><<<g, D5_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
+                    else
+                        k_vv_y_bwd_dec<false, YST, false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
                     decimated = true;
                 } else if (odd_dec) {
-                    k_vv_y_bwd_dec<false, YST, false, true><<<dim3((b.w + WAVE - 2) / (WAVE - 1), np), 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
+                    const dim3 go((b.w + WAVE - 2) / (WAVE - 1), np);
+                    if (dec5)
+                        k_vv_y_bwd_dec5<true><<<go, D5_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
+                    else
+                        k_vv_y_bwd_dec<false, YST, false, true><<<go, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
                     decimated = true;
                 } else
                     k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, nullptr, nullptr);
@@ -586,7 +604,8 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
         const int nb4 = ((xb - xa) / 4 + WAVE - 1) / WAVE, ncb = (rest + C4_THREADS - 1) / C4_THREADS;
         if (l == 0) {  // level 0: the mask is the seam's step function itself (never read from memory)
             CollapseArgs<OUT, true> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, outs,
-                                      a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, crows_of(p, 0), xa, xb, u8_words};
+                                      a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, crows_of(p, 0), xa, xb, u8_words,
+                                      p->tune.c4_lock != 0, p->tune.c4_swz != 0};
             const int strips = (a.h + A.crows - 1) / A.crows;
             const dim3 g4(nb4 + ncb * C4_SUB, strips, n);
             const bool gen = a.c4_gen && p->collapse4;
@@ -604,7 +623,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
             OutPtrs<float> eo{};
             eo.p[0] = a.e;
             CollapseArgs<float, false> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, eo,
-                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb, 1};
+                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb, 1, p->tune.c4_lock != 0, p->tune.c4_swz != 0};
             const int strips = (a.h + A.crows - 1) / A.crows;
             if (xb > xa && a.c4_gen && p->collapse4)
                 k_collapse4<float, false, false, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);

@@ -194,6 +194,13 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *   STITCH_SINGLE_FAST=1      one pair per call: run the throughput forms too (source-fused level 0, fused sweep on batched plans);
  *                             default: a lone pair, whose time is the length of its recurrence chains, not its bytes, takes the
  *                             materialised level 0 and the separate sweeps, which have the shorter chains
+ *   STITCH_Y1S=0|2            one pair in flight: causal y sweep on flat addresses (k_vv_y_fwd1) instead of scalar row offsets through a
+ *                             buffer descriptor (k_vv_y_fwd1s); 2 = the descriptor form on byte-bound level-0 launches too
+ *   STITCH_DEC5=0             one pair in flight: anticausal y sweep + decimation on two wavefronts (k_vv_y_bwd_dec) instead of two
+ *                             producers with one column per lane and three consumers (k_vv_y_bwd_dec5)
+ *   STITCH_C4_LOCKSTEP=0      k_collapse4: the channel wavefronts of a workgroup run free (default: a barrier per row keeps the index /
+ *                             mask lines they share in the caches)
+ *   STITCH_C4_SWIZZLE=0       k_collapse4: column blocks in launch order (default: contiguous runs per XCD)
  *   STITCH_GATE64=1           implicit level-0 mask, source fusion and zero-tile flags only for level heights that are multiples
  *                             of 64 (the round-2 behaviour; A/B runs)
  *   STITCH_NO_FASTDIV=1       luminance mix: always the IEEE divide (default: reciprocal + fma correction where the host has
