@@ -151,8 +151,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # STITCH_BENCH_BACKEND=gloo: a REHEARSAL of the N > 1 code of this file on a one-GPU box -- every rank drives cuda:0, the
+    # collectives run over gloo on host tensors and the mosaics are staged through host memory (MosaicGather(staged=True)).
+    # Everything else (shards, ragged blocks, coalesced sequences, verify(), the reductions) is the code the RCCL run executes.
+    # Never set by the driver; the line it produces says so (`config.backend`) and is not a scaling measurement.
+    backend = os.environ.get("STITCH_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit(f"STITCH_BENCH_BACKEND={backend}: nccl or gloo")
+    rehearsal = backend == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearsal else dev  # where the small collectives' tensors live
     # STITCH_FORCE_DIST=1 runs the N>1 code path (RCCL init, quantise, asynchronous all-gather, all-reduces) with a single
     # rank -- a rehearsal of the multi-GPU path on a one-GPU box; it is never set by the driver
     force_dist = world == 1 and os.environ.get("STITCH_FORCE_DIST") == "1"
@@ -165,17 +176,19 @@ def main():
             if force_dist:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29517")
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                dist.init_process_group(backend, rank=0, world_size=1, **({} if rehearsal else {"device_id": dev}))
+            elif rehearsal:
+                dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=dev)
             # a real collective over the communicator (creates it now, banner included, not inside the timed region):
             # every rank contributes 1, so the sum is the number of ranks RCCL actually connected
-            ones = torch.ones(1, dtype=torch.int32, device=dev)
+            ones = torch.ones(1, dtype=torch.int32, device=cdev)
             dist.all_reduce(ones)
             torch.cuda.synchronize()
             n_ranks_seen = int(ones.item())
         if n_ranks_seen != dist.get_world_size():
-            raise SystemExit(f"RCCL saw {n_ranks_seen} ranks, world size is {dist.get_world_size()}")
+            raise SystemExit(f"{backend} saw {n_ranks_seen} ranks, world size is {dist.get_world_size()}")
 
     F = args.frame
     cw, ch = pipeline.config_canvas(F)
@@ -212,7 +225,11 @@ def main():
     if use_gather:
         # finished mosaics travel as unsigned char through pipeline.MosaicGather -- the class the gloo tests cover; one block
         # of n_max mosaics per rank and step, two steps of buffers so that the gather of step k overlaps the kernels of k+1
-        gather = pipeline.MosaicGather((n_max, 3, ch, cw), dev, world, rank, slots=2 * G, force_collective=True)
+        # Input ring: (S + 1) * G blocks -- a launch sequence fills the blocks of G steps and waits for the gathers that last used
+        # them, so with S sequences in flight none of them waits for an exchange that has not even been submitted (2 * G blocks
+        # held the sequences in flight to two).  The gathered batches (world times larger) rotate through two buffers.
+        gather = pipeline.MosaicGather((n_max, 3, ch, cw), dev, world, rank, slots=(S + 1) * G, out_slots=2, force_collective=True,
+                                       staged=rehearsal)
         gstream = torch.cuda.Stream(device=dev)
 
     def run_seq(c, seq, gather_steps=None, n=None, copies=1):
@@ -280,7 +297,7 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
@@ -320,10 +337,10 @@ def main():
                         checks["bad"].append(f"{tag}: lane {ln} slot {slot} pair {i} differs from the single-pair plan")
         if gather_step is not None and not args.no_verify:
             # the gathered batch of the last step: this rank's own checksums travel by all-gather, every block is checked
-            mine = torch.tensor([ref_q.get(lo + j, 0) for j in range(n_max)], dtype=torch.int64, device=dev)
-            allq = torch.empty(world * n_max, dtype=torch.int64, device=dev)
+            mine = torch.tensor([ref_q.get(lo + j, 0) for j in range(n_max)], dtype=torch.int64, device=cdev)
+            allq = torch.empty(world * n_max, dtype=torch.int64, device=cdev)
             dist.all_gather_into_tensor(allq, mine)
-            got = gather.out[gather_step % gather.slots]
+            got = gather.gathered(gather_step)
             for r in range(world):
                 rlo, rhi = pipeline.shard_range(P, r, world)
                 for j in range(rhi - rlo):
@@ -396,9 +413,28 @@ def main():
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / 5 * 1e3
 
-    ok = torch.tensor([0 if checks["bad"] else 1], dtype=torch.int32, device=dev)
+    # ONE step -- the whole batch of P pairs, start to finish, nothing else in flight: this rank's share as its own launch
+    # sequence(s) (no coalescing with other steps), the step's exchange included when N > 1; max over ranks, best of three
+    def one_step(k):
+        evs = [run_seq(k * nb + j, seqs[j], [k] if use_gather else None) for j in range(nb)]
+        if use_gather:
+            with torch.cuda.stream(gstream):
+                for ev in evs:
+                    gstream.wait_event(ev)
+                gather.submit(k)
+
+    single_batch_ms = min(timed(lambda n_, k=k: one_step(k), 1) for k in range(3)) * 1e3
+    verify("single batch", 2 if use_gather else None)
+
+    ok = torch.tensor([0 if checks["bad"] else 1], dtype=torch.int32, device=cdev)
+    per_rank = [[n_local, nb, G, S]]
     if use_dist:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        # every rank's own schedule (ragged shards cut differently: the line reports all of them, not rank 0's)
+        mine_ = torch.tensor(per_rank[0], dtype=torch.int64, device=cdev)
+        all_ = torch.empty(dist.get_world_size() * 4, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(all_, mine_)
+        per_rank = all_.view(-1, 4).tolist()
     verified = bool(ok.item()) and not args.no_verify
     for msg in checks["bad"]:
         print(f"[bench] rank {rank}: OUTPUT CHECK FAILED: {msg}", file=sys.stderr)
@@ -406,10 +442,13 @@ def main():
     if rank == 0:
         mpix_pair = cw * ch / 1e6
         value = mpix_pair * K * P / elapsed
-        src_fused = ch % 64 == 0 and os.environ.get("STITCH_NO_SRC_FUSE") is None and os.environ.get("STITCH_NO_FUSE") is None
-        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, px_bytes, plan.fused_sweep_levels,
-                                                        fused_decimate=os.environ.get("STITCH_NO_FUSE") is None, source_fused=src_fused,
-                                                        implicit_mask=src_fused, coarse_from=plan.coarse_from)
+        # the forms the timed launch sequences ran with, from the plan and the library's per-call rule (not re-derived from the environment)
+        forms = plan.call_forms(n_seq0)
+        src_fused = "source_fused" in forms
+        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, px_bytes,
+                                                        plan.fused_sweep_levels if "fused_sweep" in forms else 0,
+                                                        fused_decimate="fused_decimate" in plan.fast_paths, source_fused=src_fused,
+                                                        implicit_mask="implicit_mask" in plan.fast_paths, coarse_from=plan.coarse_from)
         line = {
             "metric": "warp+blend MPix/s at 4096x4096x3 f32" if args.pixel == "f32" else "warp+blend MPix/s at 4096x4096x3 u8", "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
@@ -423,6 +462,12 @@ def main():
                                    f"{S} sequences in flight per GPU on separate HIP streams; canvas pixels counted",
                        "frame": [F, F, 3], "canvas": [cw, ch, 3], "levels": plan.levels, "pairs_per_step": P, "pairs_per_rank_per_step": n_local,
                        "pairs_per_sequence": B * G, "steps_per_sequence": G, "sequences_in_flight": S, "fused_sweep_levels": plan.fused_sweep_levels,
+                       "forms": sorted(forms), "backend": ("gloo REHEARSAL on one GPU: not a scaling measurement" if rehearsal else "nccl (RCCL)") if use_dist else None,
+                       "per_rank": [{"rank": r_, "pairs_per_step": v[0], "sequences_per_step": v[1], "steps_per_sequence": v[2], "lanes": v[3],
+                                     "gather_input_blocks": (v[3] + 1) * v[2] if use_gather else 0} for r_, v in enumerate(per_rank)],
+                       "single_batch_ms": round(single_batch_ms, 4),
+                       "single_batch_note": f"ONE step of {P} pairs start to finish with nothing else in flight (no coalescing with other steps"
+                                            + (", its all-gather included" if use_gather else "") + "), max over ranks, best of 3",
                        "mpix_per_pair": round(mpix_pair, 3),
                        "ms_per_pair_per_gpu": round(elapsed / K / n_local * 1e3, 4),
                        "one_sequence_in_flight_ms_per_pair": round(elapsed_one / K / n_seq0 * 1e3, 4),
@@ -468,6 +513,8 @@ def main():
             del csrc, cdst
             line["roofline"] = {"bound": "hbm", "kernel": capi.KERNEL_SYMBOLS[dom].replace("<T,", "<float,"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command run by the builder "
+                                                  "(scripts/pmc.sh); NOT measured in this run" if traffic is not None else None,
                                 "avg_launch_ms": round(ms / launches, 5), "launches": launches,
                                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                                 "share_of_device_time": round(pilot[dom][0] / pilot_tot, 4),

@@ -47,6 +47,9 @@ struct Timed {  // counts a call and its wall time
     explicit Timed(int which) : i(which) { ++g_calls[i]; }
     ~Timed() { g_secs[i] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
+// process start-up: the library's defaults go into the environment before main() -- before the program's first HIP call and
+// before it has threads (stitch_init, include/stitch.h)
+const int g_init = stitch_init();
 void check(int rc, const char* what) {
     if (rc == STITCH_OK) return;
     // The reference signals no errors on this path (degenerate inputs hang or crash it); the drop-in

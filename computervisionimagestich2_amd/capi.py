@@ -81,6 +81,7 @@ def lib():
         L.stitch_plan_workspace_bytes.restype = C.c_size_t
         L.stitch_plan_workspace_bytes.argtypes = [C.c_void_p]
         L.stitch_plan_fast_paths.argtypes = [C.c_void_p]
+        L.stitch_plan_call_forms.argtypes = [C.c_void_p, C.c_int]
         L.stitch_plan_coarse_from.argtypes = [C.c_void_p]
         L.stitch_plan_destroy.restype = None
         L.stitch_plan_destroy.argtypes = [C.c_void_p]
@@ -481,6 +482,11 @@ class Plan:
         f = lib().stitch_plan_fast_paths(self._h)
         names = ("implicit_mask", "source_fused", "fused_sweep", "zero_tiles", "fused_decimate", "coarse_levels")
         return {n for i, n in enumerate(names) if f & (1 << i)}
+
+    def call_forms(self, n_pairs=1):
+        """stitch_plan_call_forms: the per-call forms ("source_fused", "fused_sweep") a call with n_pairs pairs runs."""
+        f = lib().stitch_plan_call_forms(self._h, int(n_pairs))
+        return {n for b, n in ((2, "source_fused"), (4, "fused_sweep")) if f & b}
 
     @property
     def workspace_bytes(self):

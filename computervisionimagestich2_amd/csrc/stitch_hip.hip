@@ -31,10 +31,10 @@ thread_local std::string g_err;
 
 // The HIP runtime multiplexes streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and launch sequences on
 // streams that share a queue serialise behind each other (four sequences in flight: 1.50 ms per pair on 4 queues, 1.31 on 8).
-// The variable is read when the runtime initialises, so it is set -- only if the caller has not set it -- when this library
-// is loaded: before main() for a program linked against it, at dlopen() for a binding.  A process that initialised HIP before
-// loading the library keeps what it had.
-__attribute__((constructor)) void stitch_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+// The variable is read when the runtime initialises, so it has to be in the environment before the process's first HIP call:
+// stitch_init() (below, C ABI) puts it there -- called by whoever owns the process start-up (the C++ adaptor's static
+// initialiser, the Python package's import, bench.py), never from a library constructor: setenv() races with getenv() in a host
+// that already runs threads, and a dlopen() after HIP is up would change nothing anyway.
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -210,7 +210,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, dec5, c4_lock, c4_swz;
+        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, dec5, c4_lock, c4_swz, mover, y1n;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -240,6 +240,8 @@ struct Tuning {
         t.dec5 = env_int("STITCH_DEC5");
         t.c4_lock = env_int("STITCH_C4_LOCKSTEP");
         t.c4_swz = env_int("STITCH_C4_SWIZZLE");
+        t.mover = env_int("STITCH_MOVER");
+        t.y1n = env_int("STITCH_Y1N");
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -364,6 +366,11 @@ int launch_check(const char* what) {
     return STITCH_OK;
 }
 
+// The fused anticausal-x + causal-y sweep of a call with n pairs (see run_reduce): a per-CALL choice, like src_fused_call.
+bool fused_sweep_call(const stitch_plan* p, int n) {
+    return p->tune.wavefront >= 0 || p->tune.single_fast > 0 || n >= 2 || 7L * ((p->lv[0].h + TS - 1) / TS) >= 800;
+}
+
 // REDUCE for every level (ImageProcess.cpp:705-715): blur(G_l) into T, decimate T into G_{l+1}.
 template <typename PX>
 int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, bool src, const ZeroTiles& zi) {
@@ -386,8 +393,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
         // The band pipeline pays where a launch has many bands in flight to hide its fill (see stitch_plan_create_batched): decided
         // per CALL -- a batched plan asked for one pair runs the separate sweeps, which are faster for a lone pair (3.0 against
         // 3.4 ms at 6144 x 4096) -- unless STITCH_WAVEFRONT or STITCH_SINGLE_FAST pins the form.
-        const bool wf_call = p->tune.wavefront >= 0 || p->tune.single_fast > 0 || n >= 2 || 7L * ((p->lv[0].h + TS - 1) / TS) >= 800;
-        const bool wavefront = p->opts.blur_kind == 0 && do_x && do_y && l < p->wf_levels && wf_call;
+        const bool wavefront = p->opts.blur_kind == 0 && do_x && do_y && l < p->wf_levels && fused_sweep_call(p, n);
         // odd widths decimate inside the anticausal sweep too (three overlaps per output column); a width of 1 has no next level column
         const bool odd_dec = (a.w & 1) != 0 && a.w >= 3 && !p->no_fuse && p->tune.odd_dec != 0;
         // zero-tile flags: only where all three users run (causal x sweep, fused sweep, fused anticausal-y + decimation)
@@ -478,7 +484,25 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             } else
                 k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, state_y, nullptr, nullptr);
         } else if (p->opts.blur_kind == 0) {
-            if (do_x) {
+            // at most one workgroup of two wavefronts per two SIMDs and no source fusion: the recurrence on one wavefront, the tiles'
+            // traffic on a second (k_sweeps1.inc: chain + mover)
+            const bool mover = p->tune.mover != 0;
+            if (do_x && mover && nbx <= 512 && !(src && l == 0) && !zt.flags) {
+                // experiment switches: STITCH_MOVER=2 two tiles in the mover's registers; STITCH_Y1N=1 pads a workgroup's LDS to 84 KB (one per CU)
+                const size_t pad = p->tune.y1n == 1 ? (size_t)32 << 10 : 0;
+                {
+                    StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
+                    if (p->tune.mover == 2)
+                        k_vv_x_m<true, 2><<<nbx, 128, pad, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
+                    else
+                        k_vv_x_m<true><<<nbx, 128, pad, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
+                }
+                StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
+                if (p->tune.mover == 2)
+                    k_vv_x_m<false, 2><<<nbx, 128, pad, s>>>(p->T, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
+                else
+                    k_vv_x_m<false><<<nbx, 128, pad, s>>>(p->T, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
+            } else if (do_x) {
                 const int nb = nbx;
                 {
                     StageTimer t(p, s, src && l == 0 ? STITCH_K_VV_X_FWD_SRC : STITCH_K_VV_X_FWD, l);
@@ -498,11 +522,17 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 // fewer than 1.5 wavefronts per SIMD: the launch's time is one wavefront's chain of rows, i.e. its instructions per
                 // row (k_sweeps1.inc): one column per work-item, rows through scalar offsets, the decimation on three consumer wavefronts
                 const bool lone = (long)g.x * g.y < 1536 && !p->tune.y2, small_plane = a.ps * sizeof(float) < 0x7fffffffULL;
+                const bool ymover = mover && lone && (long)(a.pitch / WAVE) * np <= 512;  // chain + mover, 64 columns per workgroup
                 {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
-                    if (lone && small_plane && p->tune.y1s != 0 && (p->tune.y1s >= 2 || l >= 1 || a.ps * 7 * sizeof(float) * 2 < (200u << 20)))
+                    if (ymover)
+                        k_vv_y_m<true><<<dim3(a.pitch / WAVE, np), 128, p->tune.y1n == 1 ? (size_t)72 << 10 : 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk);
+                    else if (lone && small_plane && p->tune.y1s != 0 && (p->tune.y1s >= 2 || l >= 1 || a.ps * 7 * sizeof(float) * 2 < (200u << 20)))
                         // (a level-0 sweep that moves more than the chip's caches hold is bound by bytes and streams better on flat addresses)
-                        k_vv_y_fwd1s<<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
+                        if (p->tune.y1n == 8)
+                            k_vv_y_fwd1s<8><<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
+                        else
+                            k_vv_y_fwd1s<YST><<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
                     else if (lone)
                         k_vv_y_fwd1<<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
                     else
@@ -510,7 +540,9 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 }
                 StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
                 const bool dec5 = lone && small_plane && p->tune.dec5 != 0;
-                if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
+                if (ymover && p->tune.mover == 3)  // experiment: the sweep alone (in place), the decimation as its own launch (k_decimate)
+                    k_vv_y_m<false><<<dim3(a.pitch / WAVE, np), 128, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk);
+                else if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
                     if (dec5)
                         k_vv_y_bwd_dec5<false><<<g, D5_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
                     else
@@ -716,6 +748,11 @@ int run_pairs(stitch_plan* p, const PairArgs<PX>& pa, const OutPtrs<PX>& outs, i
     return STITCH_OK;
 }
 
+inline bool ranges_overlap(const void* a, size_t na, const void* b, size_t nb) {
+    const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+    return x < y + nb && y < x + na;
+}
+
 // blendTwoImages on two dense canvases: a pair whose "frame" is canvas a as it stands and whose "mosaic" is canvas b with a
 // zero shift (PairArgs::a_dense).  Source-fused plans read both canvases where level 0 is needed -- no level-0 planes, no mask
 // plane, no index plane; otherwise k_load_canvases materialises level 0.
@@ -732,7 +769,11 @@ int dev_blend(stitch_plan* p, const PX* d_a, const PX* d_b, PX* d_out, void* str
     pa.a_dense = 1;
     OutPtrs<PX> outs{};
     outs.p[0] = d_out;
-    const bool src = p->src_fuse && src_fused_call(p, 1) && (unsigned long long)p->cw * p->ch * sizeof(PX) < 0xfffffff0ULL;  // 32-bit byte offsets into a channel plane
+    const size_t bytes = sizeof(PX) * (size_t)3 * p->cw * p->ch;
+    // source-fused: a and b are read again by the causal x sweep and by the level-0 collapse WHILE d_out is written, so an output
+    // that overlaps an input takes the materialised form (k_load_canvases copies both canvases before anything is written)
+    const bool src = p->src_fuse && src_fused_call(p, 1) && (unsigned long long)p->cw * p->ch * sizeof(PX) < 0xfffffff0ULL &&  // 32-bit byte offsets into a channel plane
+                     !ranges_overlap(d_out, bytes, d_a, bytes) && !ranges_overlap(d_out, bytes, d_b, bytes);
     return run_pairs<PX>(p, pa, outs, 1, as_stream(stream), src);
 }
 
@@ -768,6 +809,12 @@ int dev_pairs(stitch_plan* p, const stitch_pair_desc* d, int n, void* stream) {
     bool src = p->src_fuse && src_fused_call(p, n);
     for (int i = 0; i < n; ++i)  // 32-bit element indices and byte offsets into one channel plane
         src = src && (unsigned long long)d[i].fw * d[i].fh * sizeof(PX) < 0xfffffff0ULL && (unsigned long long)d[i].mw * d[i].mh * sizeof(PX) < 0xfffffff0ULL;
+    // source-fused: the frames are read again while the mosaics are written (see dev_blend): no output of the call may overlap an input of it
+    const size_t ob = sizeof(PX) * (size_t)3 * p->cw * p->ch;
+    for (int i = 0; src && i < n; ++i)
+        for (int j = 0; src && j < n; ++j)
+            src = !ranges_overlap(d[i].out, ob, d[j].frame, sizeof(PX) * (size_t)3 * d[j].fw * d[j].fh) &&
+                  !ranges_overlap(d[i].out, ob, d[j].mosaic, sizeof(PX) * (size_t)3 * d[j].mw * d[j].mh);
     return run_pairs<PX>(p, pa, outs, n, as_stream(stream), src);
 }
 
@@ -1325,6 +1372,10 @@ int dev_step(const PX* d_frame, int fw, int fh, const double p_fwd[8], const dou
 extern "C" {
 
 int stitch_abi_version(void) { return STITCH_ABI_VERSION; }
+int stitch_init(void) {
+    if (std::getenv("GPU_MAX_HW_QUEUES")) return 0;
+    return setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0) == 0 ? 1 : 0;
+}
 const char* stitch_last_error(void) { return g_err.c_str(); }
 
 int stitch_device_count(void) {
@@ -1812,6 +1863,13 @@ int stitch_plan_fast_paths(const stitch_plan* p) {
     return f;
 }
 int stitch_plan_fused_sweep_levels(const stitch_plan* p) { return p ? p->wf_levels : 0; }
+int stitch_plan_call_forms(const stitch_plan* p, int n_pairs) {
+    if (!p || n_pairs < 1 || n_pairs > p->cap) return 0;
+    int f = 0;
+    if (p->src_fuse && src_fused_call(p, n_pairs)) f |= STITCH_FAST_SOURCE_FUSED;
+    if (p->wf_levels > 0 && p->opts.blur_kind == 0 && !p->blur_skip && fused_sweep_call(p, n_pairs)) f |= STITCH_FAST_FUSED_SWEEP;
+    return f;
+}
 
 int stitch_dev_pairs_u8(stitch_plan* plan, const stitch_pair_desc* pairs, int n, void* stream) {
     return dev_pairs<uint8_t>(plan, pairs, n, stream);

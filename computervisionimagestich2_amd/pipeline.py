@@ -179,14 +179,21 @@ class MosaicGather:
 
     Pairs are independent, so this end-of-pair exchange is the only communication of the batch configs."""
 
-    def __init__(self, shape, device, world, rank, slots=2, keep=False, steps=0, group=None, force_collective=False):
+    def __init__(self, shape, device, world, rank, slots=2, keep=False, steps=0, group=None, force_collective=False, out_slots=None,
+                 staged=False):
         import torch
         self.torch = torch
         self.world, self.rank, self.slots, self.keep, self.group = world, rank, slots, keep, group
         self.force_collective = force_collective  # issue the collective even with one rank (rehearsal of the N>1 path)
+        # staged (bench.py's gloo rehearsal: several ranks drive ONE GPU, the collective runs on host tensors): submit() waits for
+        # the block, moves it through host memory and returns with the gathered batch back on the device -- same buffers,
+        # same step order, same slots as the RCCL form, only synchronous.
+        self.staged = staged
         self.inp = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(slots)]
-        n_out = steps if keep else slots
-        self.out = [torch.empty((world,) + tuple(shape), dtype=torch.uint8, device=device) for _ in range(n_out)]
+        # input blocks are small (a rank's share of a step), gathered blocks are `world` times that: the input ring bounds how many
+        # launch sequences may be in flight ahead of the exchange, the output ring only has to outlive one collective
+        self.out_slots = (steps if keep else (out_slots or slots))
+        self.out = [torch.empty((world,) + tuple(shape), dtype=torch.uint8, device=device) for _ in range(self.out_slots)]
         self.works = [None] * slots
 
     def input_slot(self, k):
@@ -198,12 +205,24 @@ class MosaicGather:
             self.works[s].wait()
         return self.inp[s]
 
+    def gathered(self, k):
+        """The gathered batch of step k, [rank][...] (valid until out_slots later steps have been submitted)."""
+        return self.out[k if self.keep else k % self.out_slots]
+
     def submit(self, k):
         import torch.distributed as dist
         s = k % self.slots
-        out = self.out[k if self.keep else s]
+        out = self.gathered(k)
         if self.world == 1 and not self.force_collective:
             out[0].copy_(self.inp[s])
+            return
+        if self.staged:
+            torch = self.torch
+            torch.cuda.current_stream(self.inp[s].device).synchronize()
+            host_in = self.inp[s].cpu()
+            host_out = torch.empty((self.world,) + tuple(host_in.shape), dtype=torch.uint8)
+            dist.all_gather_into_tensor(host_out.flatten(0, 1), host_in, group=self.group)
+            out.copy_(host_out)
             return
         # output viewed as the concatenation along dim 0 (the layout every backend accepts)
         self.works[s] = dist.all_gather_into_tensor(out.flatten(0, 1), self.inp[s], group=self.group, async_op=True)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STITCH_ABI_VERSION 4
+#define STITCH_ABI_VERSION 5
 
 typedef enum stitch_status {
     STITCH_OK = 0,
@@ -65,6 +65,13 @@ typedef struct stitch_plan stitch_plan; /* device workspace of one canvas size: 
 
 /* ---- library ------------------------------------------------------------------------------------------- */
 int stitch_abi_version(void);
+/* Process start-up (optional): puts GPU_MAX_HW_QUEUES=8 into the environment unless the caller has set it -- the HIP runtime
+ * multiplexes streams onto 4 hardware queues by default and launch sequences that share a queue serialise (four sequences in
+ * flight: 1.50 -> 1.31 ms per pair).  The runtime reads the variable when it initialises, so call this BEFORE the process's
+ * first HIP call and before other threads exist (setenv is not thread-safe): the C++ adaptor does it in a static initialiser,
+ * the Python package at import.  Returns 1 if it set the variable, 0 if it was set already.  (Up to ABI 4 a constructor of
+ * the library did this at load time.) */
+int stitch_init(void);
 const char *stitch_last_error(void);
 int stitch_device_count(void);       /* number of HIP devices, 0 if none */
 int stitch_set_device(int ordinal);  /* hipSetDevice for the calling thread */
@@ -168,6 +175,13 @@ enum {
     STITCH_FAST_COARSE_LEVELS = 32
 };
 int stitch_plan_fast_paths(const stitch_plan *plan);
+/* stitch_plan_fast_paths is a CAPABILITY mask: what the workspace was built for.  Which of SOURCE_FUSED / FUSED_SWEEP a call
+ * actually runs is decided per call from its number of pairs (a launch sequence with at least two pairs and 8 MPix of canvas,
+ * or a canvas of 800 row bands, is bound by bytes and takes the fused forms; a lone pair is bound by its recurrence chains and
+ * takes the materialised level 0 and the separate sweeps; STITCH_SINGLE_FAST=1 pins the fused forms).  This returns that
+ * choice for a call with n_pairs pairs (0 for a bad argument).  An output that overlaps an input of the same call always takes
+ * the materialised level 0 (see stitch_dev_blend_*). */
+int stitch_plan_call_forms(const stitch_plan *plan, int n_pairs);
 /* First pyramid level of the COARSE_LEVELS launch (0 = none: every level has its own launch sequence). */
 int stitch_plan_coarse_from(const stitch_plan *plan);
 /* Tuning / A-B switches, read from the environment when a plan is created (none of them changes a result bit).  The
@@ -212,7 +226,11 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *                             re-runs it from there (level 0 straight from the frames); 2 = that form at the fused levels >= 1
  *                             only.  Fewer bytes, more dependent arithmetic per tile: measured slower (1) / equal (2)
  * The stitch_dev_pairs_* launch sequence contains no host synchronisation and no per-launch state in kernel
- * arguments: it may be captured into a HIP graph and replayed on new contents of the same buffers. */
+ * arguments: it may be captured into a HIP graph and replayed on new contents of the same buffers.
+ * Buffers of stitch_dev_blend_* / stitch_dev_pair(s)_*: the inputs must stay unchanged until the call has completed on its
+ * stream (the source-fused form reads them again while the output is written).  An output may alias or overlap an input of
+ * the same call -- d_out == d_b is the reference's own `result = blendTwoImages(a, result)` -- the library detects it and
+ * takes the materialised level 0 (inputs copied before anything is written), at that form's cost. */
 
 int stitch_dev_blend_u8(stitch_plan *plan, const uint8_t *d_a, const uint8_t *d_b, uint8_t *d_out, void *stream);
 int stitch_dev_blend_f32(stitch_plan *plan, const float *d_a, const float *d_b, float *d_out, void *stream);

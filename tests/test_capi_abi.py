@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(st):
     lib = st.capi.lib()
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.stitch_abi_version() == 4
+    assert lib.stitch_abi_version() == 5
 
 
 def test_pyramid_levels_host_logic(st):
