@@ -446,6 +446,14 @@ def dev_synth(w, h, frame_id, dtype, device=None):
     return out
 
 
+def dev_check_fastdiv(w):
+    """stitch_dev_check_fastdiv: (numerators tested, quotients that differ from the IEEE divide) for denominator w."""
+    lib().stitch_dev_check_fastdiv.argtypes = [C.c_float, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    t, m = C.c_ulonglong(), C.c_ulonglong()
+    _chk(lib().stitch_dev_check_fastdiv(C.c_float(w), C.byref(t), C.byref(m)))
+    return t.value, m.value
+
+
 def dev_quantize(src, out=None):
     """float mosaic -> unsigned char by truncation (CImg.h:11167-11182, behind ImageProcess.cpp:772)."""
     import torch

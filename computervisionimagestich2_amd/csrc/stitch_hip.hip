@@ -210,7 +210,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, dec5, c4_lock, c4_swz, mover, y1n;
+        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, c4_lock, c4_swz, mover, src_lone, dec7;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -237,11 +237,11 @@ struct Tuning {
         t.c4_gen = env_int("STITCH_C4_GEN");
         t.collapse_px = env_int("STITCH_COLLAPSE_PX");
         t.y1s = env_int("STITCH_Y1S");
-        t.dec5 = env_int("STITCH_DEC5");
         t.c4_lock = env_int("STITCH_C4_LOCKSTEP");
         t.c4_swz = env_int("STITCH_C4_SWIZZLE");
         t.mover = env_int("STITCH_MOVER");
-        t.y1n = env_int("STITCH_Y1N");
+        t.src_lone = env_int("STITCH_SRC_LONE_MPIX");
+        t.dec7 = env_int("STITCH_DEC7");
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -484,24 +484,23 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             } else
                 k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, state_y, nullptr, nullptr);
         } else if (p->opts.blur_kind == 0) {
-            // at most one workgroup of two wavefronts per two SIMDs and no source fusion: the recurrence on one wavefront, the tiles'
-            // traffic on a second (k_sweeps1.inc: chain + mover)
+            // few enough blocks for a workgroup of three wavefronts each (chain, loader, storer: k_sweeps1.inc) to find SIMDs of its own:
+            // the recurrence alone on one wavefront, the tiles' traffic -- and, at a source-fused level 0, the gathers -- on the others
             const bool mover = p->tune.mover != 0;
-            if (do_x && mover && nbx <= 512 && !(src && l == 0) && !zt.flags) {
-                // experiment switches: STITCH_MOVER=2 two tiles in the mover's registers; STITCH_Y1N=1 pads a workgroup's LDS to 84 KB (one per CU)
-                const size_t pad = p->tune.y1n == 1 ? (size_t)32 << 10 : 0;
+            const bool src0 = src && l == 0;
+            if (do_x && mover && !zt.flags && (nbx <= 340 || (src0 && nbx <= 1024))) {
                 {
-                    StageTimer t(p, s, STITCH_K_VV_X_FWD, l);
-                    if (p->tune.mover == 2)
-                        k_vv_x_m<true, 2><<<nbx, 128, pad, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
+                    StageTimer t(p, s, src0 ? STITCH_K_VV_X_FWD_SRC : STITCH_K_VV_X_FWD, l);
+                    if (src0)
+                        k_vv_x_m<true, PX, true><<<nbx, 192, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd, pa);
                     else
-                        k_vv_x_m<true><<<nbx, 128, pad, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
+                        k_vv_x_m<true><<<nbx, 192, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd, NoPairArgs{});
                 }
                 StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
-                if (p->tune.mover == 2)
-                    k_vv_x_m<false, 2><<<nbx, 128, pad, s>>>(p->T, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
+                if (nbx <= 340)
+                    k_vv_x_m<false><<<nbx, 192, 0, s>>>(p->T, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd, NoPairArgs{});
                 else
-                    k_vv_x_m<false><<<nbx, 128, pad, s>>>(p->T, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
+                    k_vv_x_bwd<<<nbx, 64, 0, s>>>(p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
             } else if (do_x) {
                 const int nb = nbx;
                 {
@@ -522,36 +521,34 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 // fewer than 1.5 wavefronts per SIMD: the launch's time is one wavefront's chain of rows, i.e. its instructions per
                 // row (k_sweeps1.inc): one column per work-item, rows through scalar offsets, the decimation on three consumer wavefronts
                 const bool lone = (long)g.x * g.y < 1536 && !p->tune.y2, small_plane = a.ps * sizeof(float) < 0x7fffffffULL;
-                const bool ymover = mover && lone && (long)(a.pitch / WAVE) * np <= 512;  // chain + mover, 64 columns per workgroup
+                const bool ymover = mover && lone && (long)(a.pitch / WAVE) * np <= 340;  // chain + mover, 64 columns per workgroup
                 {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
                     if (ymover)
-                        k_vv_y_m<true><<<dim3(a.pitch / WAVE, np), 128, p->tune.y1n == 1 ? (size_t)72 << 10 : 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk);
-                    else if (lone && small_plane && p->tune.y1s != 0 && (p->tune.y1s >= 2 || l >= 1 || a.ps * 7 * sizeof(float) * 2 < (200u << 20)))
-                        // (a level-0 sweep that moves more than the chip's caches hold is bound by bytes and streams better on flat addresses)
-                        if (p->tune.y1n == 8)
-                            k_vv_y_fwd1s<8><<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
-                        else
-                            k_vv_y_fwd1s<YST><<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
+                        k_vv_y_m<true><<<dim3(a.pitch / WAVE, np), 192, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk);
+                    else if (lone && small_plane && p->tune.y1s != 0 && (p->tune.y1s >= 2 || a.ps * np * sizeof(float) * 2 < (1000u << 20)))
+                        // (56 rows in flight; a sweep that moves more than ~1 GB is bound by bytes and streams better on flat addresses:
+                        // 4421 x 2315 level 0 129 -> 98 us, 6144 x 4096 level 0 266 -> 271)
+                        k_vv_y_fwd1s<8><<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
                     else if (lone)
                         k_vv_y_fwd1<<<dim3(a.pitch / WAVE, np), 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
                     else
                         k_vv_y_fwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk, nullptr);
                 }
                 StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
-                const bool dec5 = lone && small_plane && p->tune.dec5 != 0;
-                if (ymover && p->tune.mover == 3)  // experiment: the sweep alone (in place), the decimation as its own launch (k_decimate)
-                    k_vv_y_m<false><<<dim3(a.pitch / WAVE, np), 128, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk);
-                else if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
-                    if (dec5)
-                        k_vv_y_bwd_dec5<false><<<g, D5_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
+                // loader + two chains + four consumers, free-running (k_vv_y_bwd_dec7) where the launch leaves SIMDs idle; the two-wavefront
+                // kernel otherwise
+                const bool dec7 = lone && small_plane && p->tune.dec7 != 0;
+                if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
+                    if (dec7)
+                        k_vv_y_bwd_dec7<false><<<g, D7_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
                     else
                         k_vv_y_bwd_dec<false, YST, false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
                     decimated = true;
                 } else if (odd_dec) {
                     const dim3 go((b.w + WAVE - 2) / (WAVE - 1), np);
-                    if (dec5)
-                        k_vv_y_bwd_dec5<true><<<go, D5_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
+                    if (dec7)
+                        k_vv_y_bwd_dec7<true><<<go, D7_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
                     else
                         k_vv_y_bwd_dec<false, YST, false, true><<<go, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
                     decimated = true;
@@ -710,7 +707,11 @@ int check_plan_call(stitch_plan* p, const void* a, const void* b, const void* ou
 bool src_fused_call(const stitch_plan* p, int n) {
     if (p->tune.single_fast > 0) return true;
     if (7L * ((p->lv[0].h + TS - 1) / TS) >= 800) return true;
-    return n >= 2 && (long long)n * p->lv[0].w * p->lv[0].h >= 8000000LL;
+    // (round 4) one pair too: with the gathers on a loader wavefront (k_vv_x_m<.., SRC>) they are off the recurrence's issue stream,
+    // and level 0 of a canvas this size is bound by bytes even alone.  STITCH_SRC_LONE_MPIX moves the threshold (0 = never).
+    const long long lone_px = p->tune.src_lone >= 0 ? 1000000LL * p->tune.src_lone : 8000000LL;
+    if (n == 1) return p->tune.mover != 0 && lone_px > 0 && (long long)p->lv[0].w * p->lv[0].h >= lone_px && p->opts.blur_kind == 0;
+    return (long long)n * p->lv[0].w * p->lv[0].h >= 8000000LL;
 }
 
 // The launch sequence of n pairs (or of one dense-canvas blend, pa.a_dense): S1, seam scan, REDUCE, collapse.
@@ -2235,6 +2236,22 @@ int stitch_dev_synth_f32(float* d_dst, int w, int h, int frame_id, void* stream)
     if (!d_dst || w <= 0 || h <= 0 || w >= (1 << 18) || h >= (1 << 18)) return fail(STITCH_ERR_ARG, "synth: bad argument");
     k_synth<float><<<grid_xy(w, h, 3), 256, 0, as_stream(stream)>>>(d_dst, w, h, frame_id);
     return launch_check("k_synth");
+}
+int stitch_dev_check_fastdiv(float w, unsigned long long* tested, unsigned long long* mismatches) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (!(w >= 2.0f && w < 16777216.0f) || w != std::floor(w) || !tested || !mismatches) return fail(STITCH_ERR_ARG, "check_fastdiv: w must be an integer value in [2, 2^24)");
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+    k_check_fastdiv<<<4096, 256>>>(w, d, d + 1);
+    unsigned long long h[2] = {0, 0};
+    const hipError_t e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(STITCH_ERR_HIP, "check_fastdiv: %s", hipGetErrorString(e));
+    *mismatches = h[0];
+    *tested = h[1];
+    return STITCH_OK;
 }
 int stitch_dev_quantize_u8(const float* d_src, uint8_t* d_dst, size_t n, void* stream) {
     int rc = need_device();

@@ -208,10 +208,14 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *   STITCH_SINGLE_FAST=1      one pair per call: run the throughput forms too (source-fused level 0, fused sweep on batched plans);
  *                             default: a lone pair, whose time is the length of its recurrence chains, not its bytes, takes the
  *                             materialised level 0 and the separate sweeps, which have the shorter chains
- *   STITCH_Y1S=0|2            one pair in flight: causal y sweep on flat addresses (k_vv_y_fwd1) instead of scalar row offsets through a
- *                             buffer descriptor (k_vv_y_fwd1s); 2 = the descriptor form on byte-bound level-0 launches too
- *   STITCH_DEC5=0             one pair in flight: anticausal y sweep + decimation on two wavefronts (k_vv_y_bwd_dec) instead of two
- *                             producers with one column per lane and three consumers (k_vv_y_bwd_dec5)
+ *   STITCH_MOVER=0            one pair in flight: x sweeps and causal y sweep on one wavefront per block (k_vv_x_fwd / k_vv_x_bwd /
+ *                             k_vv_y_fwd1(s)) instead of chain + loader + storer wavefronts (k_vv_x_m, k_vv_y_m); also keeps a lone
+ *                             pair's level 0 materialised (the gathers of a source-fused level 0 need the loader wavefront)
+ *   STITCH_SRC_LONE_MPIX=<n>  canvas size in MPix from which ONE pair runs a source-fused level 0 (default 8; 0 = never)
+ *   STITCH_DEC7=0             one pair in flight: anticausal y sweep + decimation on two wavefronts (k_vv_y_bwd_dec) instead of the
+ *                             seven-wavefront pipeline with the short divide (k_vv_y_bwd_dec7)
+ *   STITCH_Y1S=0|2            causal y sweep on one wavefront: flat addresses (k_vv_y_fwd1) instead of scalar row offsets through a
+ *                             buffer descriptor (k_vv_y_fwd1s); 2 = the descriptor form on launches above 1 GB too
  *   STITCH_C4_LOCKSTEP=0      k_collapse4: the channel wavefronts of a workgroup run free (default: a barrier per row keeps the index /
  *                             mask lines they share in the caches)
  *   STITCH_C4_SWIZZLE=0       k_collapse4: column blocks in launch order (default: contiguous runs per XCD)
@@ -423,6 +427,12 @@ int stitch_dev_synth_f32(float *d_dst, int w, int h, int frame_id, void *stream)
 /* CImg<unsigned char>(const CImg<float>&) (CImg.h:11167-11182), the cast behind `return expand;`
  * (ImageProcess.cpp:772): the uchar mosaic of a float-frame pair, e.g. for the all-gather of finished mosaics. */
 int stitch_dev_quantize_u8(const float *d_src, uint8_t *d_dst, size_t n, void *stream);
+/* Verification hook.  The decimation divides by a level's width / height (CImg.h:29555, 29575); where the numerator lies in a
+ * range in which the IEEE sequence of gfx950 never rescales, the kernels run that sequence's multiply-adds alone with the
+ * reciprocal's refinement hoisted out (k_sweeps1.inc, fastdiv).  This call compares the short form with `numerator / w` for EVERY
+ * float bit pattern inside the range (about 2^31.4 numerators, a fraction of a second) for one denominator w (an integer value,
+ * 2 <= w < 2^24) and returns the number of numerators tested and the number of quotients that differ -- which must be 0. */
+int stitch_dev_check_fastdiv(float w, unsigned long long *tested, unsigned long long *mismatches);
 
 #ifdef __cplusplus
 }

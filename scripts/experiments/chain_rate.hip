@@ -106,6 +106,60 @@ __global__ __launch_bounds__(128) void k_b(float* out, int tiles, double f1, dou
     }
 }
 
+// D: the chain wavefront of k_vv_x_m as it is written there -- x_chain_fwd with run-time sample counts, three rotating tile buffers,
+// one workgroup barrier per tile with a second wavefront that only meets the barriers (BAR = false: no second wavefront, no barrier)
+__device__ __forceinline__ void x_chain_fwd(float* row, int jmax, bool first_tile, double f1, double f2, double f3, double& v1, double& v2, double& v3) {
+    if (first_tile) v1 = v2 = v3 = (double)row[0] / 1.7;
+    const int jfull = jmax & ~15;
+    for (int jb = 0; jb < jfull; jb += 16) {
+        float xs[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f4*>(xs + 4 * q) = *reinterpret_cast<const f4*>(row + jb + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            double v0 = (double)xs[u];
+            v0 += v1 * f1;
+            v0 += v2 * f2;
+            v0 += v3 * f3;
+            xs[u] = (float)v0;
+            v3 = v2;
+            v2 = v1;
+            v1 = v0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f4*>(row + jb + 4 * q) = *reinterpret_cast<const f4*>(xs + 4 * q);
+    }
+    for (int j = jfull; j < jmax; ++j) {
+        double v0 = (double)row[j];
+        v0 += v1 * f1;
+        v0 += v2 * f2;
+        v0 += v3 * f3;
+        row[j] = (float)v0;
+        v3 = v2;
+        v2 = v1;
+        v1 = v0;
+    }
+}
+template <bool BAR>
+__global__ __launch_bounds__(128) void k_d(float* out, int tiles, int w, double f1, double f2, double f3) {
+    __shared__ __attribute__((aligned(16))) float tl[3][64 * TP];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 3 * 64 * TP; i += blockDim.x) tl[0][i] = 1.0f + (float)(i % 7);
+    __syncthreads();
+    if (wave == 0) {
+        double v1 = 1, v2 = 1, v3 = 1;
+        for (int s = 0; s < tiles; ++s) {
+            float* row = tl[s % 3] + lane * TP;
+            const int n = min(64, w - s * 64);
+            x_chain_fwd(row, n, s == 0, f1, f2, f3, v1, v2, v3);
+            if (BAR) __syncthreads();
+        }
+        out[blockIdx.x * 64 + lane] = (float)v1;
+    } else if (BAR) {
+        for (int s = 0; s < tiles; ++s) __syncthreads();
+    }
+}
+
 template <typename F>
 float time_ms(F&& launch) {
     hipEvent_t e0, e1;
@@ -125,13 +179,17 @@ int main() {
     float* d;
     hipMalloc(&d, 2 * 1024 * 64 * sizeof(float));
     const double f1 = 1.2e-3, f2 = -3.1e-4, f3 = 7.7e-5;
-    for (int tiles : {512, 2048}) {
+    for (int tiles : {35, 512, 2048}) {
         const double n = 64.0 * tiles;
         const float a = time_ms([&] { hipLaunchKernelGGL(k_a, dim3(256), dim3(64), 0, 0, d, tiles, f1, f2, f3); });
         const float b = time_ms([&] { hipLaunchKernelGGL(k_b<false>, dim3(256), dim3(64), 0, 0, d, tiles, f1, f2, f3); });
         const float c = time_ms([&] { hipLaunchKernelGGL(k_b<true>, dim3(256), dim3(128), 0, 0, d, tiles, f1, f2, f3); });
-        printf("tiles %5d: A floats in LDS %.2f ns/sample | B doubles in LDS %.2f ns/sample | C doubles + helper wavefront %.2f ns/sample\n", tiles,
-               a * 1e6 / n, b * 1e6 / n, c * 1e6 / n);
+        const float dn = time_ms([&] { hipLaunchKernelGGL(k_d<false>, dim3(256), dim3(64), 0, 0, d, tiles, tiles * 64, f1, f2, f3); });
+        const float db = time_ms([&] { hipLaunchKernelGGL(k_d<true>, dim3(256), dim3(128), 0, 0, d, tiles, tiles * 64, f1, f2, f3); });
+        const float db2 = time_ms([&] { hipLaunchKernelGGL(k_d<true>, dim3(127), dim3(128), 0, 0, d, tiles, tiles * 64, f1, f2, f3); });
+        printf("tiles %5d: A floats in LDS %.2f ns/sample | B doubles in LDS %.2f ns/sample | C doubles + helper wavefront %.2f ns/sample | D k_vv_x_m's chain, no barrier %.2f, "
+               "barrier with an idle wavefront %.2f (127 workgroups: %.2f)\n", tiles,
+               a * 1e6 / n, b * 1e6 / n, c * 1e6 / n, dn * 1e6 / n, db * 1e6 / n, db2 * 1e6 / n);
     }
     return 0;
 }

@@ -898,3 +898,11 @@ def test_host_entry_points_from_six_threads_mixed(st, gpu, oracle):
     [t.join(timeout=300) for t in th]
     assert not any(t.is_alive() for t in th), "a thread is stuck"
     assert not errs, errs[:5]
+
+
+@pytest.mark.parametrize("w", [2, 3, 5, 7, 63, 64, 100, 263, 527, 540, 1081, 2210, 2315, 4096, 4421, 6144, 16384, 24576, 16777215])
+def test_fastdiv_equals_ieee_divide(st, w):
+    """The decimation's divide by a level's width / height in its short form (hoisted reciprocal refinement, five instructions,
+    k_sweeps1.inc) against the IEEE divide for EVERY numerator bit pattern inside the short form's range."""
+    tested, bad = st.capi.dev_check_fastdiv(float(w))
+    assert tested > 2 ** 31 and bad == 0, (w, tested, bad)
