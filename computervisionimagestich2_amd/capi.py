@@ -638,6 +638,13 @@ class Band:
         _chk(lib().stitch_band_reduce_y_bwd(self._h, int(level), int(plane), _dp(fwd_state), _dp(resume) if resume is not None else None,
                                             _dp(state_out), _stream()))
 
+    def reduce_y_fwd_cols(self, level, x0, x1, resume, state_out):
+        _chk(lib().stitch_band_reduce_y_fwd_cols(self._h, int(level), int(x0), int(x1), _dp(resume) if resume is not None else None, _dp(state_out), _stream()))
+
+    def reduce_y_bwd_cols(self, level, x0, x1, fwd_state, resume, state_out):
+        _chk(lib().stitch_band_reduce_y_bwd_cols(self._h, int(level), int(x0), int(x1), _dp(fwd_state), _dp(resume) if resume is not None else None,
+                                                 _dp(state_out), _stream()))
+
     def rows(self, level, kind, first_row, nrows, buf, to_buffer):
         assert buf.is_cuda and buf.is_contiguous() and buf.dtype.is_floating_point and buf.element_size() == 4
         _chk(lib().stitch_band_rows(self._h, int(level), int(kind), int(first_row), int(nrows), _dp(buf), int(bool(to_buffer)), _stream()))

@@ -371,7 +371,7 @@ class BandStitcher:
       * the bands of the first replicated level are all-gathered and the coarse levels run on every rank;
       * before a split level is collapsed, two halo rows of G and E of the level above come from either neighbour."""
 
-    def __init__(self, cw, ch, split_levels, transport, device, opts=None, fuse_sweeps=None, plane_pipeline_min=None):
+    def __init__(self, cw, ch, split_levels, transport, device, opts=None, fuse_sweeps=None, plane_pipeline_min=None, col_chunks=1):
         import torch
         self.t, self.dev = transport, device
         # the anticausal x sweep fused with the causal y sweep on the two finest levels (stitch_band_reduce_xy_fwd: one pass over a
@@ -397,6 +397,18 @@ class BandStitcher:
         self.per_plane = [pmin is not None and self.world > 1 and g["rows"] * g["pitch"] >= pmin for g in self.geom[:-1]]
         if self.per_plane[0]:
             self.band.set_level0(False)  # one plane at a time: level 0 must exist as planes
+        # col_chunks = C > 1: the state crosses ranks in C column chunks (stitch_band_reduce_y_*_cols): columns are independent in a y
+        # sweep, so rank r+1 starts on chunk c while rank r sweeps chunk c+1 and the chain of a level is N + C - 1 chunk-sweeps long
+        # instead of N sweeps.  Levels with an odd width, the plane-by-plane form and the fused sweep keep one chunk.
+        self.chunks = []
+        for l, g in enumerate(self.geom[:-1]):
+            C = 1 if (col_chunks <= 1 or g["w"] % 2 or self.per_plane[l] or (self.fuse_sweeps and l < 2)) else int(col_chunks)
+            step = -(-g["pitch"] // (128 * C)) * 128  # columns per chunk: a multiple of 128
+            self.chunks.append([(x0, min(x0 + step, g["pitch"])) for x0 in range(0, g["pitch"], step)] if C > 1 else None)
+        pad = lambda n: -(-n // 128) * 128  # the chunk's state arrays have the launch's width: 128 columns per workgroup
+        self.cst_f = [[torch.zeros(4 * 7 * pad(x1 - x0), **f64) for x0, x1 in ch_] if ch_ else None for ch_ in self.chunks]
+        self.cst_b = [[torch.zeros(3 * 7 * pad(x1 - x0), **f64) for x0, x1 in ch_] if ch_ else None for ch_ in self.chunks]
+        self.cres = [[torch.zeros(3 * 7 * pad(x1 - x0), **f64) for x0, x1 in ch_] if ch_ else None for ch_ in self.chunks]
         self.st_fp = [torch.zeros((7, 4 * g["pitch"]), **f64) if pp else None for pp, g in zip(self.per_plane, self.geom[:-1])]
         self.st_bp = [torch.zeros((7, 3 * g["pitch"]), **f64) if pp else None for pp, g in zip(self.per_plane, self.geom[:-1])]
         self.res_p = [torch.zeros((7, 3 * g["pitch"]), **f64) if pp else None for pp, g in zip(self.per_plane, self.geom[:-1])]
@@ -446,6 +458,19 @@ class BandStitcher:
                         yield ("send", self.st_bp[l][pl], r - 1)
                 continue
             fuse = self.fuse_sweeps and l < 2  # as in a plan: the fused sweep on the two finest levels only (it loses on small levels)
+            if self.chunks[l]:
+                B.reduce_x(l)
+                for c, (x0, x1) in enumerate(self.chunks[l]):  # causal sweep chunk by chunk, rank 0 first
+                    res = (yield ("recv", self.cres[l][c], r - 1)) if r > 0 else None
+                    B.reduce_y_fwd_cols(l, x0, x1, res, self.cst_f[l][c])
+                    if r < N - 1:
+                        yield ("send", self.cst_f[l][c][:self.cres[l][c].numel()], r + 1)
+                for c, (x0, x1) in enumerate(self.chunks[l]):  # anticausal sweep + decimation chunk by chunk, last rank first
+                    res = (yield ("recv", self.cres[l][c], r + 1)) if r < N - 1 else None
+                    B.reduce_y_bwd_cols(l, x0, x1, self.cst_f[l][c], res, self.cst_b[l][c])
+                    if r > 0:
+                        yield ("send", self.cst_b[l][c], r - 1)
+                continue
             if not fuse:
                 B.reduce_x(l)
             # causal sweep, rank 0 first; then the anticausal sweep + decimation, last rank first.  A band's sweep is one chain
@@ -501,12 +526,12 @@ class LocalBandGroup:
     (8 bands at 24576 x 16384: 57 ms with host-staged hand-offs from 8 threads, 38.5 ms with device hand-offs from 8 threads,
     this class: see profiles/r03_config5_band.json)."""
 
-    def __init__(self, cw, ch, split_levels, world, device, opts=None, fuse_sweeps=None, plane_pipeline_min=None):
+    def __init__(self, cw, ch, split_levels, world, device, opts=None, fuse_sweeps=None, plane_pipeline_min=None, col_chunks=1):
         import collections
         import torch
         self.world, self.dev = world, device
         self.streams = [torch.cuda.Stream(device=device) for _ in range(world)]
-        self.bands = [BandStitcher(cw, ch, split_levels, _Addr(r, world), device, opts, fuse_sweeps, plane_pipeline_min) for r in range(world)]
+        self.bands = [BandStitcher(cw, ch, split_levels, _Addr(r, world), device, opts, fuse_sweeps, plane_pipeline_min, col_chunks) for r in range(world)]
         self.box = collections.defaultdict(collections.deque)  # (src, dst) -> posted (tensor, event), FIFO
 
     def close(self):

@@ -410,6 +410,14 @@ int stitch_band_reduce_y_fwd(stitch_band *band, int level, int plane, const doub
  * state_out: [3][pitch] for the rank above */
 int stitch_band_reduce_y_bwd(stitch_band *band, int level, int plane, const double *d_fwd_state, const double *d_resume,
                              double *d_state_out, void *stream);
+/* The two y sweeps over the COLUMN RANGE [x0, x1) of all seven planes (x0, x1 multiples of 128; x1 may be the level's pitch), with the
+ * chunk's own state arrays: resume [3][7][x1-x0], state_out [4][7][x1-x0] (causal) / [3][7][x1-x0] (anticausal); fwd_state: the chunk's
+ * causal state_out.  A rank hands a chunk's state on as soon as the chunk is swept, so the ranks pipeline over the chunks: the chain
+ * of a level is ranks + chunks - 1 chunk-sweeps long instead of `ranks` whole sweeps.  The anticausal form
+ * needs an even level width. */
+int stitch_band_reduce_y_fwd_cols(stitch_band *band, int level, int x0, int x1, const double *d_resume, double *d_state_out, void *stream);
+int stitch_band_reduce_y_bwd_cols(stitch_band *band, int level, int x0, int x1, const double *d_fwd_state, const double *d_resume,
+                                  double *d_state_out, void *stream);
 /* band rows <-> dense buffer [planes][nrows][w]; kind 0: G a,b (6 planes), 1: E (3), 2: G + mask (7); first_row band-local,
  * -halo .. rows+halo-1; to_buffer != 0 packs, 0 unpacks */
 int stitch_band_rows(stitch_band *band, int level, int kind, int first_row, int nrows, float *d_buf, int to_buffer, void *stream);

@@ -132,7 +132,7 @@ def test_pair_split_into_row_bands_threads(st, gpu, oracle, world, fw, fh, cw, c
 
 @pytest.mark.parametrize("world,fw,fh,cw,ch,Ls,dt", [(2, 1408, 1024, 2048, 1024, 3, "u8"), (3, 520, 384, 768, 384, 2, "f32"), (8, 1408, 1024, 2048, 1024, 2, "f32"),
                                                       (6, 520, 384, 772, 384, 1, "u8")])
-@pytest.mark.parametrize("fuse", [True, False, "planes", "stored", "stored+fused"])
+@pytest.mark.parametrize("fuse", [True, False, "planes", "stored", "stored+fused", "chunks4"])
 def test_band_group_single_host_thread(st, gpu, oracle, world, fw, fh, cw, ch, Ls, dt, fuse):
     """pipeline.LocalBandGroup: all bands of a pair on one device, their launch sequences (BandStitcher.steps) interleaved by ONE
     host thread, hand-offs as device copies ordered by events -- the same generator a rank of its own executes over RCCL.  Two
@@ -146,7 +146,8 @@ def test_band_group_single_host_thread(st, gpu, oracle, world, fw, fh, cw, ch, L
     A, B, P = _inputs(oracle, fw, fh, dtype)
     rc, ref = oracle.pair(B, P, 0.0, 0.0, A, 0, 0, cw, ch)
     assert rc == 0
-    grp = pipeline.LocalBandGroup(cw, ch, Ls, world, gpu, fuse_sweeps=fuse in (True, "stored+fused"), plane_pipeline_min=0 if fuse == "planes" else None)
+    grp = pipeline.LocalBandGroup(cw, ch, Ls, world, gpu, fuse_sweeps=fuse in (True, "stored+fused"), plane_pipeline_min=0 if fuse == "planes" else None,
+                                  col_chunks=4 if fuse == "chunks4" else 1)  # "chunks4": the y states cross bands in four column chunks
     if str(fuse).startswith("stored"):  # level 0 as seven stored planes (k_compose + k_mask) instead of source-fused
         for b in grp.bands:
             b.band.set_level0(False)
@@ -163,11 +164,13 @@ def test_band_group_single_host_thread(st, gpu, oracle, world, fw, fh, cw, ch, L
 def test_band_random_configs(st, gpu, oracle):
     """Seeded random band splits against the oracle: 1-4 ranks, 1-3 split levels, even and odd canvas widths (odd widths keep the
     separate anticausal sweep + decimation and no zero-tile flags), both pixel types, every form of the reduce (fused sweep with
-    and without neighbours, separate sweeps, stored level 0, plane-by-plane hand-off), frames that cover part of the canvas."""
+    and without neighbours, separate sweeps, stored level 0, plane-by-plane hand-off, the state handed over in 2, 3 or 5 column chunks),
+    frames that cover part of the canvas."""
     import torch
     from computervisionimagestich2_amd import pipeline
     rng = np.random.default_rng(int(os.environ.get("FUZZ_BANDS_SEED", "20261006")))
-    forms = [dict(fuse_sweeps=True), dict(fuse_sweeps=False), dict(fuse_sweeps=None), dict(fuse_sweeps=False, plane_pipeline_min=0), dict(fuse_sweeps=True, stored=True)]
+    forms = [dict(fuse_sweeps=True), dict(fuse_sweeps=False), dict(fuse_sweeps=None), dict(fuse_sweeps=False, plane_pipeline_min=0), dict(fuse_sweeps=True, stored=True),
+             dict(fuse_sweeps=False, col_chunks=2), dict(fuse_sweeps=False, col_chunks=3, stored=True), dict(fuse_sweeps=None, col_chunks=5)]
     ran, skipped = 0, []
     n_cases = int(os.environ.get("FUZZ_BANDS", "30"))  # FUZZ_BANDS=500 FUZZ_BANDS_SEED=n: a campaign
     for case in range(n_cases):
