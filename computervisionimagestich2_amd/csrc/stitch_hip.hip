@@ -210,7 +210,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, c4_lock, c4_swz, mover, src_lone, dec7;
+        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, c4_lock, c4_swz, mover, src_lone, dec7, xbym, xbym_mpix, coarse_lds;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -242,6 +242,9 @@ struct Tuning {
         t.mover = env_int("STITCH_MOVER");
         t.src_lone = env_int("STITCH_SRC_LONE_MPIX");
         t.dec7 = env_int("STITCH_DEC7");
+        t.xbym = env_int("STITCH_XBYM");
+        t.xbym_mpix = env_int("STITCH_XBYM_MPIX");
+        t.coarse_lds = env_int("STITCH_COARSE_LDS");
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -258,6 +261,7 @@ struct Level {
     int c4_gen;        // != 0: [0, c4_xb) with per-lane tap offsets (k_collapse4 GEN) -- chosen where it covers more than the fixed pattern
 };
 
+constexpr int CO_LDS_BYTES = 144 * 1024;  // dynamic LDS k_coarse_lds may take (160 KB per CU, 15 KB of tables beside it)
 constexpr int WF_CTRL_WORDS = 4 * 16 + 16;  // band-queue heads of up to 4 levels (64 bytes apart) + the abort word
 constexpr int WF_STICKY_WORDS = 16;         // behind them, outside what a launch sequence clears: the plan's count of timed-out waits
 
@@ -297,6 +301,8 @@ struct stitch_plan {
     // STITCH_RECOMPUTE=0 keeps the two-pass form.
     int recompute = 0;  // 0 off, 1 every wavefront level, 2 the wavefront levels >= 1 only
     double* ckpt = nullptr;  // [3][tiles of level 0][lines of level 0]
+    unsigned long long* xy_dbg = nullptr;  // STITCH_XBYM_STAMP=1: k_vv_xby_m's per-tile stamps of one band of the last level-0 launch (diagnostics)
+    int xy_dbg_nc = 0;
     unsigned long long* wf_dbg = nullptr;  // STITCH_WAVEFRONT_STAMP=1: [wf_max_wgs][8] segment cycle sums (diagnostics)
     // pinned copy of the plan's sticky count of timed-out hand-off waits, refreshed at the end of every call.  The device
     // word only grows (no launch sequence clears it), so the last copy covers every earlier queued call as well.
@@ -371,11 +377,23 @@ bool fused_sweep_call(const stitch_plan* p, int n) {
     return p->tune.wavefront >= 0 || p->tune.single_fast > 0 || n >= 2 || 7L * ((p->lv[0].h + TS - 1) / TS) >= 800;
 }
 
+// One pair in flight: the anticausal x and the causal y sweep of level l as ONE launch of five-wavefront bands (k_vv_xby_m) where the
+// separate launches are bound by their bytes -- from STITCH_XBYM_MPIX megapixels per plane (default 20: 6144 x 4096).  Below that a level's time is
+// its chain of rows and columns either way, and the fused form adds a hand-off per 64-row band.  STITCH_XBYM=0: never; =1: the first
+// four levels of every lone pair, whatever their size (tests).
+bool lone_fused_level(const stitch_plan* p, int n, int l) {
+    const Level& a = p->lv[l];
+    const long mpix = p->tune.xbym > 0 ? 0 : p->tune.xbym_mpix >= 0 ? p->tune.xbym_mpix : 20;
+    return n == 1 && p->wf_ctrl && l < 4 && p->opts.blur_kind == 0 && !p->blur_skip && p->tune.mover != 0 && p->tune.xbym != 0 && a.w > 1 && a.h > 1 &&
+           (long)a.w * a.h >= mpix * 1000000L && (a.h + TS - 1) / TS < 4095 && !fused_sweep_call(p, n);
+}
+
 // REDUCE for every level (ImageProcess.cpp:705-715): blur(G_l) into T, decimate T into G_{l+1}.
 template <typename PX>
 int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, bool src, const ZeroTiles& zi) {
     const int np = 7 * n;  // planes in flight: every launch covers all pairs of the batch
-    if (p->wf_levels > 0) k_clear_words<<<1, 256, 0, s>>>((u64*)p->wf_ctrl, WF_CTRL_WORDS / 2);  // band-queue heads + abort flag
+    const bool any_lone_fused = lone_fused_level(p, n, 0);  // levels shrink: level 0 qualifies whenever any level does
+    if (p->wf_levels > 0 || any_lone_fused) k_clear_words<<<1, 256, 0, s>>>((u64*)p->wf_ctrl, WF_CTRL_WORDS / 2);  // band-queue heads + abort flag
     const int l_end = p->coarse_from > 0 ? p->coarse_from : p->L - 1;  // levels [0, l_end) are reduced level by level
     for (int l = 0; l < l_end; ++l) {
         const Level& a = p->lv[l];
@@ -488,6 +506,8 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
             // the recurrence alone on one wavefront, the tiles' traffic -- and, at a source-fused level 0, the gathers -- on the others
             const bool mover = p->tune.mover != 0;
             const bool src0 = src && l == 0;
+            const bool xby = do_x && do_y && lone_fused_level(p, n, l);
+            const double* ystate = p->state;  // where the causal y sweep leaves its state for the anticausal one
             if (do_x && mover && !zt.flags && (nbx <= 340 || (src0 && nbx <= 1024))) {
                 {
                     StageTimer t(p, s, src0 ? STITCH_K_VV_X_FWD_SRC : STITCH_K_VV_X_FWD, l);
@@ -497,7 +517,8 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                         k_vv_x_m<true><<<nbx, 192, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd, NoPairArgs{});
                 }
                 StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
-                if (nbx <= 340)
+                if (xby) {
+                } else if (nbx <= 340)
                     k_vv_x_m<false><<<nbx, 192, 0, s>>>(p->T, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd, NoPairArgs{});
                 else
                     k_vv_x_bwd<<<nbx, 64, 0, s>>>(p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
@@ -510,19 +531,42 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                     else
                         k_vv_x_fwd<PX, false><<<nb, 64, 0, s>>>(a.g, p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, NoPairArgs{}, zt, ZeroTiles{}, nullptr, bd);
                 }
-                {
+                if (!xby) {
                     StageTimer t(p, s, STITCH_K_VV_X_BWD, l);
                     k_vv_x_bwd<<<nb, 64, 0, s>>>(p->T, a.w, a.pitch, lines, p->vvk, p->state, mk, bd);
                 }
             } else
                 HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * np, hipMemcpyDeviceToDevice, s));
+            if (xby) {
+                Wavefront wf{};
+                wf.yg = p->wf_yg;
+                wf.counter = p->wf_ctrl + (size_t)l * 16;
+                wf.abort = p->wf_ctrl + WF_CTRL_WORDS - 16;
+                wf.sticky = p->wf_ctrl + WF_CTRL_WORDS;
+                wf.spin_limit = p->wf_spin_limit;
+                wf.NR = NR;
+                wf.NC = (a.w + TS - 1) / TS;
+                wf.NP = np;
+                wf.epoch = 1;
+                wf.mask_l0 = mk.enabled;
+                if (p->xy_dbg && l == 0) wf.dbg = p->xy_dbg, p->xy_dbg_nc = wf.NC;
+                // every polled word is cleared in front of the launch (see the batch form above)
+                const size_t gran_words = (size_t)wf.NP * wf.NC * WF_GRAN * WAVE;
+                k_clear_words<<<(int)std::min<size_t>((gran_words + 255) / 256, 2048), 256, 0, s>>>(p->wf_yg, gran_words);
+                // the x state lives in state[0 .. 4 * lines); the y state the kernel leaves goes behind it
+                double* state_y = p->state + 4 * (size_t)p->cap * 7 * (a.h + 64);
+                ystate = state_y;
+                StageTimer t(p, s, STITCH_K_VV_XBYF, l);
+                // two workgroups per CU by LDS: every band of a lone 6144 x 4096 pair (448) is resident at once
+                k_vv_xby_m<<<(int)std::min<long>((long)wf.NP * wf.NR, 512), XY_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf);
+            }
             if (do_y) {
                 dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
                 // fewer than 1.5 wavefronts per SIMD: the launch's time is one wavefront's chain of rows, i.e. its instructions per
                 // row (k_sweeps1.inc): one column per work-item, rows through scalar offsets, the decimation on three consumer wavefronts
                 const bool lone = (long)g.x * g.y < 1536 && !p->tune.y2, small_plane = a.ps * sizeof(float) < 0x7fffffffULL;
                 const bool ymover = mover && lone && (long)(a.pitch / WAVE) * np <= 340;  // chain + mover, 64 columns per workgroup
-                {
+                if (!xby) {
                     StageTimer t(p, s, STITCH_K_VV_Y_FWD, l);
                     if (ymover)
                         k_vv_y_m<true><<<dim3(a.pitch / WAVE, np), 192, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, mk);
@@ -541,19 +585,19 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 const bool dec7 = lone && small_plane && p->tune.dec7 != 0;
                 if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
                     if (dec7)
-                        k_vv_y_bwd_dec7<false><<<g, D7_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
+                        k_vv_y_bwd_dec7<false><<<g, D7_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps);
                     else
-                        k_vv_y_bwd_dec<false, YST, false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
+                        k_vv_y_bwd_dec<false, YST, false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
                     decimated = true;
                 } else if (odd_dec) {
                     const dim3 go((b.w + WAVE - 2) / (WAVE - 1), np);
                     if (dec7)
-                        k_vv_y_bwd_dec7<true><<<go, D7_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps);
+                        k_vv_y_bwd_dec7<true><<<go, D7_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps);
                     else
-                        k_vv_y_bwd_dec<false, YST, false, true><<<go, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, p->state, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
+                        k_vv_y_bwd_dec<false, YST, false, true><<<go, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
                     decimated = true;
                 } else
-                    k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, p->state, nullptr, nullptr);
+                    k_vv_y_bwd<<<g, 64, 0, s>>>(p->T, a.h, a.pitch, a.ps, p->vvk, ystate, nullptr, nullptr);
             }
         } else {
             HIPCHK(hipMemcpyAsync(p->T, a.g, sizeof(float) * a.ps * np, hipMemcpyDeviceToDevice, s));
@@ -583,9 +627,28 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
         ca.T = p->T;
         ca.k = p->vvk;
         ca.dbg = p->co_dbg;
-        k_coarse<<<n, CO_THREADS, 0, s>>>(ca);
+        // every level in LDS where they fit (k_coarse_lds): G of all levels, the blur scratch, the collapse chain; rows pitched odd
+        CoarseLds lo{};
+        int fl = 0, tabs_w = 0, tabs_h = 0;
+        for (int i = 0; i < ca.n; ++i) {
+            lo.p[i] = ca.lv[i].w | 1;
+            lo.g[i] = fl;
+            fl += 7 * ca.lv[i].h * lo.p[i];
+            lo.e[i] = fl;
+            fl += 3 * ca.lv[i].h * lo.p[i];
+            if (i + 1 < ca.n) tabs_w += ca.lv[i].w, tabs_h += ca.lv[i].h;
+        }
+        lo.t = fl;
+        fl += 7 * ca.lv[0].h * lo.p[0];
+        const size_t lds_bytes = sizeof(float) * (size_t)fl;
+        if (p->tune.coarse_lds != 0 && !p->co_dbg && lds_bytes <= CO_LDS_BYTES && tabs_w <= CO_TABN && tabs_h <= CO_TABN) {
+            static std::once_flag once;  // more than 64 KB of dynamic LDS is opt-in per function
+            std::call_once(once, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_lds), hipFuncAttributeMaxDynamicSharedMemorySize, CO_LDS_BYTES); });
+            k_coarse_lds<<<n, CO_THREADS, lds_bytes, s>>>(ca, lo);
+        } else
+            k_coarse<<<n, CO_THREADS, 0, s>>>(ca);
     }
-    if (p->wf_levels > 0) HIPCHK(hipMemcpyAsync(p->h_wf_abort, p->wf_ctrl + WF_CTRL_WORDS, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    if (p->wf_levels > 0 || any_lone_fused) HIPCHK(hipMemcpyAsync(p->h_wf_abort, p->wf_ctrl + WF_CTRL_WORDS, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     return launch_check("reduce");
 }
 
@@ -634,7 +697,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
         if (l == 0) {  // level 0: the mask is the seam's step function itself (never read from memory)
             CollapseArgs<OUT, true> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, outs,
                                       a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, crows_of(p, 0), xa, xb, u8_words,
-                                      p->tune.c4_lock > 0, p->tune.c4_swz != 0};
+                                      p->tune.c4_lock > 0, p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
             const int strips = (a.h + A.crows - 1) / A.crows;
             const dim3 g4(nb4 + ncb * C4_SUB, strips, n);
             const bool gen = a.c4_gen && p->collapse4;
@@ -652,7 +715,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
             OutPtrs<float> eo{};
             eo.p[0] = a.e;
             CollapseArgs<float, false> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, eo,
-                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb, 1, p->tune.c4_lock > 0, p->tune.c4_swz != 0};
+                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb, 1, p->tune.c4_lock > 0, p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
             const int strips = (a.h + A.crows - 1) / A.crows;
             if (xb > xa && a.c4_gen && p->collapse4)
                 k_collapse4<float, false, false, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
@@ -1610,8 +1673,10 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     wf_levels = std::min(wf_levels, L - 1);
     while (wf_levels > 0 && (lw[wf_levels - 1] < 2 || lh[wf_levels - 1] < 2)) --wf_levels;
     const int NC0 = (v0.w + TS - 1) / TS;
-    const size_t yg_off = wf_levels ? take(sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE) : 0;
-    const size_t wfc_off = wf_levels ? take(sizeof(unsigned) * (WF_CTRL_WORDS + WF_STICKY_WORDS)) : 0;
+    // (a plan without fused-sweep levels keeps them for k_vv_xby_m: one pair in flight, from STITCH_XBYM_MPIX megapixels per level)
+    const bool wf_alloc = wf_levels > 0 || (o.blur_kind == 0 && !tn.no_fuse && o.sigma >= 0.5f && L >= 2);
+    const size_t yg_off = wf_alloc ? take(sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE) : 0;
+    const size_t wfc_off = wf_alloc ? take(sizeof(unsigned) * (WF_CTRL_WORDS + WF_STICKY_WORDS)) : 0;
     const size_t zi_off = take((size_t)B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS));
     const size_t zt_off = wf_levels ? take((size_t)7 * B * ((v0.h + TS - 1) / TS) * ((v0.w + TS - 1) / TS)) : 0;
     int recompute = 0;  // opt-in: level 0 re-run from the frames measured 3 % slower, the plane levels within noise
@@ -1645,10 +1710,18 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     p->state = reinterpret_cast<double*>(base + st_off);
     p->d_seam = reinterpret_cast<SeamDev*>(base + seam_off);
     p->wf_levels = wf_levels;
-    if (wf_levels) {
+    if (wf_alloc) {
         p->wf_yg = reinterpret_cast<u64*>(base + yg_off);
         p->wf_yg_bytes = sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE;
         p->wf_ctrl = reinterpret_cast<unsigned*>(base + wfc_off);
+        if (tn.xbyf_spin_limit >= 0) p->wf_spin_limit = (unsigned)tn.xbyf_spin_limit;
+    }
+    if (wf_alloc && std::getenv("STITCH_XBYM_STAMP") &&
+        (hipMalloc((void**)&p->xy_dbg, sizeof(unsigned long long) * 5 * NC0) != hipSuccess || hipMemset(p->xy_dbg, 0, sizeof(unsigned long long) * 5 * NC0) != hipSuccess)) {
+        (void)hipGetLastError();
+        p->xy_dbg = nullptr;
+    }
+    if (wf_levels) {
         p->zt = reinterpret_cast<uint8_t*>(base + zt_off);
         p->zi = reinterpret_cast<uint8_t*>(base + zi_off);
         p->recompute = recompute;
@@ -1720,7 +1793,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         }
     }
     std::memset(p->h_seam, 0, sizeof(SeamDev) * B);
-    if (wf_levels) {
+    if (wf_alloc) {
         if (hipHostMalloc((void**)&p->h_wf_abort, sizeof(unsigned)) != hipSuccess) {
             stitch_plan_destroy(p);
             return fail(STITCH_ERR_HIP, "plan_create: pinned allocation failed");
@@ -1743,6 +1816,21 @@ void stitch_plan_destroy(stitch_plan* p) {
     if (p->arena) (void)hipFree(p->arena);
     if (p->h_seam) (void)hipHostFree(p->h_seam);
     if (p->h_wf_abort) (void)hipHostFree(p->h_wf_abort);
+    if (p->xy_dbg) {
+        const int nc = p->xy_dbg_nc;
+        std::vector<unsigned long long> h((size_t)5 * std::max(nc, 1));
+        if (nc > 0 && hipMemcpy(h.data(), p->xy_dbg, sizeof(unsigned long long) * 5 * nc, hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char* nm[5] = {"x chain", "y chain", "loader", "storer", "courier"};
+            const unsigned long long t0 = h[2 * (size_t)nc];  // the loader's first tile
+            std::fprintf(stderr, "[k_vv_xby_m stamps, middle band of plane 0, last level-0 launch: ticks since the loader's first tile / 1000, per tile]\n");
+            for (int wv = 0; wv < 5; ++wv) {
+                std::fprintf(stderr, "  %-8s", nm[wv]);
+                for (int j = 0; j < nc; j += std::max(1, nc / 24)) std::fprintf(stderr, " %6.1f", ((double)h[(size_t)wv * nc + j] - (double)t0) * 1e-3);
+                std::fprintf(stderr, " | last %6.1f\n", ((double)h[(size_t)wv * nc + nc - 1] - (double)t0) * 1e-3);
+            }
+        }
+        (void)hipFree(p->xy_dbg);
+    }
     if (p->co_dbg) {
         unsigned long long h[CO_MAXL * 8];
         if (hipMemcpy(h, p->co_dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1869,6 +1957,7 @@ int stitch_plan_call_forms(const stitch_plan* p, int n_pairs) {
     int f = 0;
     if (p->src_fuse && src_fused_call(p, n_pairs)) f |= STITCH_FAST_SOURCE_FUSED;
     if (p->wf_levels > 0 && p->opts.blur_kind == 0 && !p->blur_skip && fused_sweep_call(p, n_pairs)) f |= STITCH_FAST_FUSED_SWEEP;
+    if (lone_fused_level(p, n_pairs, 0)) f |= STITCH_FAST_FUSED_SWEEP;  // one pair in flight: k_vv_xby_m
     return f;
 }
 

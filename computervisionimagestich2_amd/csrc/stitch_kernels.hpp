@@ -87,6 +87,7 @@ __device__ __forceinline__ void bilinear3(const PX* __restrict__ src, int w, int
 #include "k_sweeps.inc"  // Van Vliet recursive Gaussian: causal / anticausal x and y sweeps, fused anticausal-y + decimation (B3, B4)
 #include "k_sweeps1.inc"  // the y sweeps with one column per lane and scalar row offsets: launches that leave SIMDs idle (one pair in flight)
 #include "k_fused_sweep.inc"  // the fused anticausal-x + causal-y sweep: row bands as pipeline stages (k_vv_xbyf)
+#include "k_fused_sweep1.inc"  // the same for one pair in flight: five wavefronts per band (k_vv_xby_m)
 #include "k_pyramid.inc"  // Deriche blur, stand-alone decimation, expand / Laplacian / blend / collapse (B3', B4-B6)
 #include "k_coarse.inc"  // all levels below a size threshold in one launch: REDUCE to the top, top blend, collapse back up
 #include "k_equalize.inc"  // equalisation and luminance mix (E1-E3, M1)

@@ -218,8 +218,14 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *                             buffer descriptor (k_vv_y_fwd1s); 2 = the descriptor form on launches above 1 GB too
  *   STITCH_C4_LOCKSTEP=1      k_collapse4: the three channel wavefronts of a workgroup meet at a barrier every row (measured: the index /
  *                             mask lines they share are NOT what the kernel over-fetches -- 0.7 % fewer bytes, no time; default off)
- *   STITCH_C4_SWIZZLE=0       k_collapse4: column blocks in launch order (default: within eight strips every XCD gets one whole strip,
- *                             so that the source lines neighbouring blocks share are fetched into one L2)
+ *   STITCH_C4_SWIZZLE=0|2     k_collapse4: 0 = column blocks in launch order (default 1: within eight strips every XCD gets one whole
+ *                             strip, so that the source lines neighbouring blocks share are fetched into one L2); 2 = every XCD walks
+ *                             its own run of adjacent strips top to bottom (the rows two strips share meet in one L2 too)
+ *   STITCH_XBYM=0|1           one pair in flight: anticausal x + causal y sweep of a level as ONE launch of five-wavefront bands
+ *                             (k_vv_xby_m): 0 = never, 1 = at the first four levels whatever their size (tests); default: where the
+ *                             separate sweeps are bound by their bytes, from STITCH_XBYM_MPIX megapixels per plane (default 20)
+ *   STITCH_XBYM_STAMP=1       diagnostics: per-tile time stamps of the five wavefronts of one band of k_vv_xby_m, printed at plan destruction
+ *   STITCH_COARSE_LDS=0       coarse levels in global memory (k_coarse) instead of LDS (k_coarse_lds, where the levels fit into 144 KB)
  *   STITCH_GATE64=1           implicit level-0 mask, source fusion and zero-tile flags only for level heights that are multiples
  *                             of 64 (the round-2 behaviour; A/B runs)
  *   STITCH_NO_FASTDIV=1       luminance mix: always the IEEE divide (default: reciprocal + fma correction where the host has

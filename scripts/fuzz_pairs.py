@@ -24,7 +24,7 @@ SWITCHES = {"STITCH_WAVEFRONT": [None, "0", "1", "2"], "STITCH_RECOMPUTE": [None
             "STITCH_COLLAPSE4": [None, "0"], "STITCH_NO_ZERO_TILES": [None, "1"], "STITCH_NO_SRC_FUSE": [None, "1"],
             "STITCH_GATE64": [None, None, "1"], "STITCH_COARSE": [None, None, "0", "40", "300"],
             "STITCH_SINGLE_FAST": [None, "1"], "STITCH_ODD_DEC": [None, None, "0"], "STITCH_C4_GEN": [None, None, "0"], "STITCH_COLLAPSE_PX": [None, None, "0"],
-            "STITCH_Y1S": [None, None, "0", "2"], "STITCH_DEC7": [None, None, "0"], "STITCH_MOVER": [None, None, "0"], "STITCH_SRC_LONE_MPIX": [None, None, "0", "1"], "STITCH_C4_LOCKSTEP": [None, None, "0"], "STITCH_C4_SWIZZLE": [None, None, "0"]}
+            "STITCH_Y1S": [None, None, "0", "2"], "STITCH_DEC7": [None, None, "0"], "STITCH_MOVER": [None, None, "0"], "STITCH_SRC_LONE_MPIX": [None, None, "0", "1"], "STITCH_C4_LOCKSTEP": [None, None, "0"], "STITCH_C4_SWIZZLE": [None, None, "0", "2"], "STITCH_XBYM": [None, "0", "1", "1"], "STITCH_COARSE_LDS": [None, None, "0"]}
 
 
 def _case(case, rng, O, capi, torch, dev, bad, done, verbose):
