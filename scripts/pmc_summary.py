@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel sums of every counter in the rocprofv3 --pmc passes of scripts/pmc.sh -> profiles/r03_pmc_summary.csv (or the path given as second argument)."""
+"""Per-kernel sums of every counter in the rocprofv3 --pmc passes of scripts/pmc.sh -> profiles/r04_pmc_summary.csv (or the path given as second argument)."""
 import collections
 import csv
 import glob
@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
-out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04_pmc_summary.csv")
 rows = collections.defaultdict(lambda: [0, 0.0])
 for f in sorted(glob.glob(os.path.join(src, "*", "runc", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
