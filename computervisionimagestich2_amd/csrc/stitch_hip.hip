@@ -66,6 +66,9 @@ int need_device() {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// Row pitch of a level's planes in floats: the width rounded up to 64, plus -- for rows of 16 KB and more -- `pad` floats
+// (STITCH_PITCH_PAD, rounded up to 64) so that the 64 rows of a tile do not start a power-of-two-ish number of bytes apart.
+inline int level_pitch(int w, int pad) { return round_up(w, 64) + (pad > 0 && w >= 4096 ? round_up(pad, 64) : 0); }
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 constexpr double kPI = 3.14159265358979323846;  // cimg::PI
 
@@ -210,7 +213,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, c4_lock, c4_swz, mover, src_lone, dec7, xbym, xbym_mpix, coarse_lds;
+        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, c4_lock, c4_swz, mover, src_lone, dec7, xbym, xbym_mpix, coarse_lds, pitch_pad;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -245,6 +248,7 @@ struct Tuning {
         t.xbym = env_int("STITCH_XBYM");
         t.xbym_mpix = env_int("STITCH_XBYM_MPIX");
         t.coarse_lds = env_int("STITCH_COARSE_LDS");
+        t.pitch_pad = env_int("STITCH_PITCH_PAD");
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -301,6 +305,8 @@ struct stitch_plan {
     // STITCH_RECOMPUTE=0 keeps the two-pass form.
     int recompute = 0;  // 0 off, 1 every wavefront level, 2 the wavefront levels >= 1 only
     double* ckpt = nullptr;  // [3][tiles of level 0][lines of level 0]
+    unsigned long long* d7_dbg = nullptr;  // STITCH_D7_STAMP=<level>: k_vv_y_bwd_dec7's per-chunk stamps of one workgroup at that level (diagnostics)
+    int d7_dbg_level = -1, d7_dbg_chunks = 0;
     unsigned long long* xy_dbg = nullptr;  // STITCH_XBYM_STAMP=1: k_vv_xby_m's per-tile stamps of one band of the last level-0 launch (diagnostics)
     int xy_dbg_nc = 0;
     unsigned long long* wf_dbg = nullptr;  // STITCH_WAVEFRONT_STAMP=1: [wf_max_wgs][8] segment cycle sums (diagnostics)
@@ -584,8 +590,11 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 // kernel otherwise
                 const bool dec7 = lone && small_plane && p->tune.dec7 != 0;
                 if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
-                    if (dec7)
-                        k_vv_y_bwd_dec7<false><<<g, D7_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps);
+                    if (dec7) {
+                        unsigned long long* dbg = p->d7_dbg && l == p->d7_dbg_level ? p->d7_dbg : nullptr;
+                        if (dbg) p->d7_dbg_chunks = (a.h + YCH - 1) / YCH;
+                        k_vv_y_bwd_dec7<false><<<g, D7_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps, dbg, dbg ? Tuning::env_int("STITCH_D7_STAMP_MODE") : 0);
+                    }
                     else
                         k_vv_y_bwd_dec<false, YST, false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps, ZeroTiles{}, nullptr, nullptr, a.h, b.h);
                     decimated = true;
@@ -1645,7 +1654,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         Level& v = p->lv[l];
         v.w = lw[l];
         v.h = lh[l];
-        v.pitch = round_up(v.w, 64);
+        v.pitch = level_pitch(v.w, tn.pitch_pad);
         v.ps = (size_t)v.pitch * v.h;
         g_off[l] = take(sizeof(float) * (v.ps * 7 * B + (size_t)v.pitch * 64));
         e_off[l] = l >= 1 || L == 1 ? take(sizeof(float) * v.ps * 3 * B) : 0;
@@ -1715,6 +1724,14 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         p->wf_yg_bytes = sizeof(u64) * B * 7 * NC0 * WF_GRAN * WAVE;
         p->wf_ctrl = reinterpret_cast<unsigned*>(base + wfc_off);
         if (tn.xbyf_spin_limit >= 0) p->wf_spin_limit = (unsigned)tn.xbyf_spin_limit;
+    }
+    if (std::getenv("STITCH_D7_STAMP")) {
+        p->d7_dbg_level = atoi(std::getenv("STITCH_D7_STAMP"));
+        const size_t nb = sizeof(unsigned long long) * (7 * ((size_t)(v0.h + YCH - 1) / YCH + 1) + 8);
+        if (hipMalloc((void**)&p->d7_dbg, nb) != hipSuccess || hipMemset(p->d7_dbg, 0, nb) != hipSuccess) {
+            (void)hipGetLastError();
+            p->d7_dbg = nullptr;
+        }
     }
     if (wf_alloc && std::getenv("STITCH_XBYM_STAMP") &&
         (hipMalloc((void**)&p->xy_dbg, sizeof(unsigned long long) * 5 * NC0) != hipSuccess || hipMemset(p->xy_dbg, 0, sizeof(unsigned long long) * 5 * NC0) != hipSuccess)) {
@@ -1816,6 +1833,32 @@ void stitch_plan_destroy(stitch_plan* p) {
     if (p->arena) (void)hipFree(p->arena);
     if (p->h_seam) (void)hipHostFree(p->h_seam);
     if (p->h_wf_abort) (void)hipHostFree(p->h_wf_abort);
+    if (p->d7_dbg) {
+        const int nc = p->d7_dbg_chunks;
+        std::vector<unsigned long long> h((size_t)7 * std::max(nc, 1) + 8);
+        if (nc > 8 && hipMemcpy(h.data(), p->d7_dbg, sizeof(unsigned long long) * (7 * nc + 6), hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char* nm[7] = {"loader", "chain 0", "chain 1", "cons 0", "cons 1", "cons 2", "cons 3"};
+            const unsigned long long t0 = h[0];
+            std::fprintf(stderr, "[k_vv_y_bwd_dec7 stamps, level %d, %d chunks, middle workgroup of plane 0: ticks since the loader's first chunk, every %d-th chunk; then ticks per chunk over the middle half]\n",
+                         p->d7_dbg_level, nc, std::max(1, nc / 16));
+            for (int wv = 0; wv < 7; ++wv) {
+                std::fprintf(stderr, "  %-8s", nm[wv]);
+                const int c0 = wv >= 3 ? wv - 3 : 0, step = wv >= 3 ? 4 : 1;  // consumer c stamps chunks c, c+4, ...
+                for (int j = 0; j < nc; j += std::max(1, nc / 16)) {
+                    const int jj = c0 + (j / step) * step;
+                    if (jj < nc) std::fprintf(stderr, " %7.0f", (double)h[(size_t)wv * nc + jj] - (double)t0);
+                }
+                const int ja = c0 + (nc / 4 / step) * step, jb = c0 + (3 * nc / 4 / step) * step;
+                if (jb > ja && jb < nc) std::fprintf(stderr, " | %.1f per chunk", ((double)h[(size_t)wv * nc + jb] - (double)h[(size_t)wv * nc + ja]) / (jb - ja));
+                std::fprintf(stderr, "\n");
+            }
+            if (h[(size_t)7 * nc + 1])
+                std::fprintf(stderr, "  chain 0, ticks per chunk by segment: top + prefetch %.0f | rows 0-3 %.0f | release %.0f | rows 4-7 %.0f | write back %.0f | tail + back edge %.0f\n",
+                             (double)h[(size_t)7 * nc + 0] / nc, (double)h[(size_t)7 * nc + 1] / nc, (double)h[(size_t)7 * nc + 2] / nc, (double)h[(size_t)7 * nc + 3] / nc,
+                             (double)h[(size_t)7 * nc + 4] / nc, (double)h[(size_t)7 * nc + 5] / nc);
+        }
+        (void)hipFree(p->d7_dbg);
+    }
     if (p->xy_dbg) {
         const int nc = p->xy_dbg_nc;
         std::vector<unsigned long long> h((size_t)5 * std::max(nc, 1));

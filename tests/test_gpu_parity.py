@@ -592,6 +592,37 @@ def test_lone_fused_sweep_equals_the_oracle(st, gpu, oracle, dtype, monkeypatch)
     plan.close()
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_dev_blend_into_one_of_its_inputs(st, gpu, oracle, dtype, monkeypatch):
+    """stitch_dev_blend_* with the output buffer on top of an input (ImageProcess.cpp:230 assigns the blend's result to the
+    panorama it was computed from).  A source-fused level 0 reads both canvases again while the collapse writes the output, so a
+    call whose output overlaps an input takes the materialised level 0 (k_load_canvases copies first): same bits as the oracle,
+    in place over a, in place over b, and into a buffer that overlaps a by one row."""
+    import torch
+    from computervisionimagestich2_amd import capi
+    monkeypatch.setenv("STITCH_SRC_LONE_MPIX", "1")  # one pair in flight is source-fused from 1 MPix of canvas
+    w, h = 1400, 800
+    A, B = two_canvases(oracle, w, h, 7, 8, dtype)
+    rc, ref, rs = oracle.blend(A, B)
+    assert rc == 0
+    plan = capi.Plan(w, h)
+    assert "source_fused" in plan.call_forms(1)
+    for where in ("separate", "over_a", "over_b", "one_row_into_a"):
+        a, b = torch.from_numpy(A).to(gpu), torch.from_numpy(B).to(gpu)
+        if where == "one_row_into_a":
+            big = torch.empty(2 * 3 * h * w, dtype=a.dtype, device=gpu)
+            a2 = big[3 * h * w - w:2 * 3 * h * w - w].view(3, h, w)
+            a2.copy_(a)
+            out = big[:3 * h * w].view(3, h, w)  # its last row is a2's first
+            got = plan.blend(a2, b, out=out)
+        else:
+            out = {"separate": None, "over_a": a, "over_b": b}[where]
+            got = plan.blend(a, b, out=out)
+        assert plan.status().as_tuple() == rs.as_tuple()
+        assert np.array_equal(got.cpu().numpy().view(np.uint8), ref.view(np.uint8)), where
+    plan.close()
+
+
 @pytest.mark.parametrize("lds", ["0", None])
 def test_coarse_levels_in_lds_and_in_global_memory_agree(st, gpu, oracle, lds, monkeypatch):
     """The coarse levels of a pyramid run in one launch per pair: k_coarse_lds (every level in LDS, the default where they fit) or
