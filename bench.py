@@ -361,6 +361,16 @@ def main():
     drain()
     log("warm-up done")
     verify("warm-up", (W - 1) if (use_gather and W > 0) else None)
+    # A hand-off time-out in the WARM-UP (seen once in several hundred runs: the first launch sequence on a fresh plan, every later
+    # one on the same plan correct) is reported in the line (`warmup_handoff_faults`) and the warm-up is run once more; the timed
+    # regions are never retried -- a fault there fails the run.
+    warmup_faults = [m for m in checks["bad"] if "hand-off wait" in m]
+    if warmup_faults and not use_gather:
+        print(f"[bench] rank {rank}: hand-off time-out during the warm-up, warm-up repeated once: {warmup_faults[0]}", file=sys.stderr, flush=True)
+        checks["bad"] = []
+        run_steps(0, W, use_gather)
+        drain()
+        verify("warm-up (second attempt)", None)
 
     # pilot (lane 0, every launch bracketed by HIP events; ~10 % overhead, so never the timed region): per-kernel
     # table and the choice of the dominant kernel
@@ -479,6 +489,7 @@ def main():
                                     f"next step) inside the timed region: {n_max * 3 * ch * cw * (world - 1) / 1e9:.2f} GB into every rank per step")
                                    if use_gather else "none (one rank holds the whole batch)" if world == 1 else "none (--no-gather)",
                        "no_exchange_mpix_s": round(mpix_pair * K * P / elapsed_noex, 2) if elapsed_noex else None,
+                       "warmup_handoff_faults": len(warmup_faults),
                        "output_check": {"timed_regions_checked": checks["regions"], "buffers_compared": checks["buffers"],
                                         "against": "single-pair plan (separate launch sequence), bit for bit; status() of every plan and pair",
                                         "failures": len(checks["bad"])},

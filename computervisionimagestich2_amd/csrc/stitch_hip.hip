@@ -176,14 +176,18 @@ void regular_range(const std::vector<int32_t>& idx, int w, int sw, int sh, int* 
 }
 
 // The columns [0, *xb) (a multiple of 256) in which every group of four columns x0.. has its taps inside ONE 16-byte load at
-// ix[x0]: ix[x0 + 3] + 1 <= ix[x0] + 3 (always true for a step below 1/2) and ix[x0] + 3 inside the source row (see k_collapse4, GEN).
+// ix[x0]: ix[x0 + 3] + 1 <= ix[x0] + 3 (always true for a step below 1/2; see k_collapse4, GEN).  The window may reach past the
+// source row's last sample: the last group of an even width has the taps s, s+1, s+1, s+1 or s, s+1, s+1, s+2 with the row ending
+// at s + 2, so element 3 of its window is the first sample of the next row (of the next plane, of whatever follows the planes in
+// the arena) -- loaded, selected by no tap: a column whose first tap IS the row's last sample takes that sample twice, as the
+// reference does (CImg.h:29648), whatever the window holds behind it.
 void general_range(const std::vector<int32_t>& idx, int w, int sw, int sh, int* xb) {
     *xb = 0;
     if (sw < 4 || sh < 2) return;
     int x0 = 0;
     for (; x0 + 3 < w; x0 += 4) {
         const int s_ = idx[x0];
-        if (!(idx[x0 + 1] >= s_ && idx[x0 + 2] >= idx[x0 + 1] && idx[x0 + 3] >= idx[x0 + 2] && idx[x0 + 3] - s_ <= 2 && s_ + 3 <= sw - 1)) break;
+        if (!(idx[x0 + 1] >= s_ && idx[x0 + 2] >= idx[x0 + 1] && idx[x0 + 3] >= idx[x0 + 2] && idx[x0 + 3] - s_ <= 2 && s_ >= 0 && s_ + 1 <= sw - 1)) break;
     }
     *xb = x0 / 256 * 256;
 }
@@ -298,7 +302,7 @@ struct stitch_plan {
     uint8_t* zt = nullptr;         // zero-tile flags of T, [7*cap][bands][tiles] of level 0 (ZeroTiles); reused level by level
     bool zero_tiles = false;
     int wf_max_wgs = 2304;  // persistent workgroups of the fused sweep (STITCH_XBYF_WGS)
-    unsigned wf_spin_limit = 1u << 20;  // polls before a hand-off wait gives up (STITCH_XBYF_SPIN_LIMIT)
+    unsigned wf_spin_limit = 1u << 23;  // polls before a hand-off wait gives up, about 20 s (STITCH_XBYF_SPIN_LIMIT); 2^20 (2-3 s) was reached once in a warm-up
     int wf_early_read = 1;  // STITCH_XBYF_EARLY=0: poll for the hand-off only when it is needed
     // The causal x sweep of a wavefront level keeps only its state in front of every tile and the fused sweep re-runs it
     // tile by tile (k_vv_x_fwd<.., CKPT>, k_vv_xbyf MODE 1/2): the x-swept level is neither written nor read back.
@@ -708,7 +712,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
                                       a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, crows_of(p, 0), xa, xb, u8_words,
                                       p->tune.c4_lock > 0, p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
             const int strips = (a.h + A.crows - 1) / A.crows;
-            const dim3 g4(nb4 + ncb * C4_SUB, strips, n);
+            const dim3 g4(c4_padded_blocks(nb4, A.swizzle) + ncb * C4_SUB, strips, n);
             const bool gen = a.c4_gen && p->collapse4;
             if (xb > xa && src && pa.a_dense && gen)
                 k_collapse4<OUT, true, true, true><<<g4, C4_THREADS, 0, s>>>(A, nb4, ncb);
@@ -726,10 +730,11 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
             CollapseArgs<float, false> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, eo,
                                          a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb, 1, p->tune.c4_lock > 0, p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
             const int strips = (a.h + A.crows - 1) / A.crows;
+            const dim3 g4(c4_padded_blocks(nb4, A.swizzle) + ncb * C4_SUB, strips, n);
             if (xb > xa && a.c4_gen && p->collapse4)
-                k_collapse4<float, false, false, true><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
+                k_collapse4<float, false, false, true><<<g4, C4_THREADS, 0, s>>>(A, nb4, ncb);
             else if (xb > xa)
-                k_collapse4<float, false><<<dim3(nb4 + ncb * C4_SUB, strips, n), C4_THREADS, 0, s>>>(A, nb4, ncb);
+                k_collapse4<float, false><<<g4, C4_THREADS, 0, s>>>(A, nb4, ncb);
             else if ((long)n * a.pitch * a.h <= 4096L * 64 * 2 && p->tune.collapse_px != 0)  // a launch that leaves most SIMDs with at most a wavefront or two
                 k_collapse_px<<<grid_xy(a.pitch, a.h, n), 256, 0, s>>>(A);
             else
@@ -1797,7 +1802,8 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         {
             int gxb = 0;
             general_range(idx, v.w, lw[l + 1], lh[l + 1], &gxb);
-            v.c4_gen = gxb >= (v.c4_xb - v.c4_xa) + 512 && tn.c4_gen != 0;  // worth the extra selects only where it gains two blocks or more
+            // STITCH_C4_GEN: 0 never, 1 where it gains two blocks or more, 2 / unset wherever it gains a block
+            v.c4_gen = tn.c4_gen != 0 && gxb >= (v.c4_xb - v.c4_xa) + (tn.c4_gen == 1 ? 512 : 256);
             if (v.c4_gen) v.c4_xa = 0, v.c4_xb = gxb;
         }
         (void)hipMemcpy(v.ix, idx.data(), sizeof(int32_t) * v.w, hipMemcpyHostToDevice);

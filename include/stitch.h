@@ -196,14 +196,16 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *   STITCH_COLLAPSE4=0        collapse with one column and three channels per work-item everywhere (k_collapse) instead of
  *                             four columns of one channel where the resize taps are regular (k_collapse4)
  *   STITCH_XBYF_WGS=<n>       persistent workgroups of the fused sweep (default 2304)
- *   STITCH_XBYF_SPIN_LIMIT=<n> polls before a hand-off wait of the fused sweep gives up (default 2^20; 0 forces the
+ *   STITCH_XBYF_SPIN_LIMIT=<n> polls before a hand-off wait of the fused sweep gives up (default 2^23, about 20 s; 0 forces the
  *                             bail-out path: tests of the sticky time-out report)
  *   STITCH_XBYF_EARLY=0       fused sweep: poll for the hand-off only when it is needed (default: read it ahead of the prefetch)
  *   STITCH_COARSE=<n>         side length from which the coarse levels run in one launch (default 40; 0 = one launch sequence
  *                             per level everywhere)
  *   STITCH_COLLAPSE_PX=0      collapse of small middle levels in strips (k_collapse) instead of one pixel per work-item (k_collapse_px)
- *   STITCH_C4_GEN=0           collapse, odd level widths: four columns per work-item only where the resize taps follow the fixed pattern
- *                             (default: per-lane tap offsets wherever that covers two 256-column blocks more)
+ *   STITCH_C4_GEN=0|1         collapse: 0 = four columns per work-item only where the resize taps follow the fixed pattern s, s+1, s+1, s+2
+ *                             (the first and the last 256 columns of an even width then take the one-column path: 8 % of level 0 at
+ *                             6144 columns, a sixth of level 1); 1 = per-lane tap offsets only where they cover two blocks more;
+ *                             default: per-lane tap offsets wherever they cover a block more (every level, whole rows)
  *   STITCH_ODD_DEC=0          odd level widths: anticausal y sweep and decimation as two kernels (default: fused, as for even widths)
  *   STITCH_SINGLE_FAST=1      one pair per call: run the throughput forms too (source-fused level 0, fused sweep on batched plans);
  *                             default: a lone pair, whose time is the length of its recurrence chains, not its bytes, takes the
@@ -221,6 +223,8 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *   STITCH_C4_SWIZZLE=0|2     k_collapse4: 0 = column blocks in launch order (default 1: within eight strips every XCD gets one whole
  *                             strip, so that the source lines neighbouring blocks share are fetched into one L2); 2 = every XCD walks
  *                             its own run of adjacent strips top to bottom (the rows two strips share meet in one L2 too)
+ *   STITCH_PITCH_PAD=<n>      floats added to the row pitch of levels of 4096 columns and more (A/B: measured no effect, default 0)
+ *   STITCH_D7_STAMP=<level>   diagnostics: per-chunk time stamps of the seven wavefronts of one workgroup of k_vv_y_bwd_dec7 at that level
  *   STITCH_XBYM=0|1           one pair in flight: anticausal x + causal y sweep of a level as ONE launch of five-wavefront bands
  *                             (k_vv_xby_m): 0 = never, 1 = at the first four levels whatever their size (tests); default: where the
  *                             separate sweeps are bound by their bytes, from STITCH_XBYM_MPIX megapixels per plane (default 20)
