@@ -710,7 +710,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
         if (l == 0) {  // level 0: the mask is the seam's step function itself (never read from memory)
             CollapseArgs<OUT, true> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, outs,
                                       a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, crows_of(p, 0), xa, xb, u8_words,
-                                      p->tune.c4_lock > 0, p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
+                                      std::max(0, p->tune.c4_lock), p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
             const int strips = (a.h + A.crows - 1) / A.crows;
             const dim3 g4(c4_padded_blocks(nb4, A.swizzle) + ncb * C4_SUB, strips, n);
             const bool gen = a.c4_gen && p->collapse4;
@@ -728,7 +728,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
             OutPtrs<float> eo{};
             eo.p[0] = a.e;
             CollapseArgs<float, false> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, eo,
-                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb, 1, p->tune.c4_lock > 0, p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
+                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb, 1, std::max(0, p->tune.c4_lock), p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
             const int strips = (a.h + A.crows - 1) / A.crows;
             const dim3 g4(c4_padded_blocks(nb4, A.swizzle) + ncb * C4_SUB, strips, n);
             if (xb > xa && a.c4_gen && p->collapse4)

@@ -218,8 +218,10 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *                             seven-wavefront pipeline with the short divide (k_vv_y_bwd_dec7)
  *   STITCH_Y1S=0|2            causal y sweep on one wavefront: flat addresses (k_vv_y_fwd1) instead of scalar row offsets through a
  *                             buffer descriptor (k_vv_y_fwd1s); 2 = the descriptor form on launches above 1 GB too
- *   STITCH_C4_LOCKSTEP=1      k_collapse4: the three channel wavefronts of a workgroup meet at a barrier every row (measured: the index /
- *                             mask lines they share are NOT what the kernel over-fetches -- 0.7 % fewer bytes, no time; default off)
+ *   STITCH_C4_LOCKSTEP=1|2    k_collapse4: 1 = the three channel wavefronts of a workgroup meet at a barrier every row (measured: the index /
+ *                             mask lines they share are NOT what the kernel over-fetches -- 0.7 % fewer bytes, no time); 2 = levels >= 1:
+ *                             channel 0 reads the mask samples of a row and hands them to the other two through LDS (2 % fewer bytes,
+ *                             no time); default off
  *   STITCH_C4_SWIZZLE=0|2     k_collapse4: 0 = column blocks in launch order (default 1: within eight strips every XCD gets one whole
  *                             strip, so that the source lines neighbouring blocks share are fetched into one L2); 2 = every XCD walks
  *                             its own run of adjacent strips top to bottom (the rows two strips share meet in one L2 too)

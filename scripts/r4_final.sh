@@ -11,7 +11,7 @@ python bench.py --steps 20 --warmup 5 --pairs-per-step 4 --no-cpu-baseline > $o/
 STITCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --pairs-per-step 4 --no-cpu-baseline > $o/bench_p4_forcedist.json 2> $o/bench_p4_forcedist.err
 python bench.py --steps 20 --warmup 5 --pixel u8 --no-cpu-baseline > $o/bench_u8.json 2> $o/bench_u8.err
 STITCH_C4_SWIZZLE=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single > $o/bench_noswizzle.json 2> $o/bench_noswizzle.err
-STITCH_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline > $o/bench_2rank_rehearsal.json 2> $o/bench_2rank_rehearsal.err
+STITCH_BENCH_BACKEND=gloo python bench.py --gpus 2 --pairs-per-step 8 --steps 10 --warmup 2 --no-cpu-baseline > $o/bench_2rank_rehearsal.json 2> $o/bench_2rank_rehearsal.err
 for f in bench bench_p4 bench_p4_forcedist bench_u8 bench_noswizzle bench_2rank_rehearsal; do python - $o/$f.json <<'PY'
 import json,sys
 try:
