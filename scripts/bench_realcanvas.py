@@ -83,7 +83,9 @@ F, M = capi.dev_synth(fw, fh, 1, tdt, dev), capi.dev_synth(cw - fw // 2, ch - 7,
 P = [1.0, 0.002, 1e-6, -(cw - fw - 3.0), -0.001, 1.0, 5e-7, -3.5]
 batch = {"canvas": [cw, ch], "pixel": "f32", "pairs_per_sequence": 8, "sequences_in_flight": 4}
 ref = None
-for label, env in VARIANTS[:2]:
+# (each variant twice, alternating, the better time kept: the same plans run up to 11 % slower in some placements of their
+# workspaces -- scripts/experiments/exp_batch4421.py -- and the second set created in a process used to be such a one)
+for label, env in VARIANTS[:2] * 2:
     use(env)
     lanes = [(capi.Plan(cw, ch, max_pairs=8), torch.cuda.Stream(device=dev), [torch.empty((3, ch, cw), dtype=tdt, device=dev) for _ in range(8)]) for _ in range(4)]
     batch[label + "_paths"] = sorted(lanes[0][0].fast_paths)
@@ -93,7 +95,9 @@ for label, env in VARIANTS[:2]:
             with torch.cuda.stream(st):
                 plan.pairs([(F, P, -0.25, -1.5, M, 0, -2, o) for o in outs_])
 
-    ms = timed(go, n=10, warm=3)
+    ms = timed(go, n=20, warm=3)
+    batch.setdefault(label + "_ms_per_pair_runs", []).append(round(ms / 32, 4))
+    ms = min(batch[label + "_ms_per_pair_runs"]) * 32
     batch[label + "_ms_per_pair"] = round(ms / 32, 4)
     batch[label + "_mpix_s"] = round(cw * ch / 1e6 / (ms / 32) * 1e3, 1)
     for plan, st, outs_ in lanes:
