@@ -454,6 +454,14 @@ def dev_check_fastdiv(w):
     return t.value, m.value
 
 
+def dev_check_collapse_taps(w, h, probe):
+    """stitch_dev_check_collapse_taps: (samples compared, samples that differ between k_collapse4's per-lane taps and k_collapse)."""
+    lib().stitch_dev_check_collapse_taps.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    t, m = C.c_ulonglong(), C.c_ulonglong()
+    _chk(lib().stitch_dev_check_collapse_taps(int(w), int(h), int(probe), C.byref(t), C.byref(m)))
+    return t.value, m.value
+
+
 def dev_quantize(src, out=None):
     """float mosaic -> unsigned char by truncation (CImg.h:11167-11182, behind ImageProcess.cpp:772)."""
     import torch

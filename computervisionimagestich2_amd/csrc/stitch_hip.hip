@@ -2391,6 +2391,82 @@ int stitch_dev_check_fastdiv(float w, unsigned long long* tested, unsigned long 
     *tested = h[1];
     return STITCH_OK;
 }
+int stitch_dev_check_collapse_taps(int w, int h, int probe, unsigned long long* compared, unsigned long long* mismatches) {
+    int rc = need_device();
+    if (rc) return rc;
+    if (w < 256 || (w & 1) || h < 4 || (h & 1) || w > 16384 || h > 16384 || probe < 0 || probe > 1 || !compared || !mismatches)
+        return fail(STITCH_ERR_ARG, "check_collapse_taps: even w >= 256, even h >= 4 (both <= 16384), probe 0 or 1");
+    const int sw = w / 2, sh = h / 2, pitch = round_up(w, 64), spitch = round_up(sw, 64);
+    const size_t ps = (size_t)pitch * h, sps = (size_t)spitch * sh;
+    std::vector<int32_t> ix, iy;
+    std::vector<double> ax, ay;
+    expand_table(sw, w, ix, ax);
+    expand_table(sh, h, iy, ay);
+    int xa = 0, xb = 0, gxb = 0;
+    regular_range(ix, w, sw, sh, &xa, &xb);
+    general_range(ix, w, sw, sh, &gxb);
+    if (gxb < 256) return fail(STITCH_ERR_ARG, "check_collapse_taps: no block of this width takes the four-column path");
+    // level l: a, b and the mask; level l+1: G (a, b) and E.  probe 0: pseudo-random finite samples of both signs.  probe 1, the signed-zero
+    // probe: G_l = -0, G_{l+1} = +0 (every Laplacian sample -0), E_{l+1} = -0 except the FIRST sample of every row = 5: a column whose first tap
+    // is a row's last sample must come out -0 (the reference takes that sample twice: -0 + 0 * -0); had it taken the sample the 16-byte
+    // window holds behind it (the next row's 5) the sum would be +0.
+    std::vector<float> g(7 * ps + (size_t)pitch * 64, 0.f), gn(7 * sps + (size_t)spitch * 64, 0.f), en(3 * sps + (size_t)spitch * 64, 0.f);
+    uint32_t lcg = 0x5717C4EDu ^ (uint32_t)(w * 31 + h);
+    auto rnd = [&]() {
+        lcg = lcg * 1664525u + 1013904223u;
+        return ((int)(lcg >> 8) % 60001 - 30000) / 117.0f;
+    };
+    for (size_t q = 0; q < 7; ++q)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) g[q * ps + (size_t)y * pitch + x] = q == 6 ? (probe ? 0.5f : (float)((x * 7 + y * 3) % 11) / 10.f) : probe ? -0.0f : rnd();
+    for (size_t q = 0; q < 7; ++q)
+        for (int y = 0; y < sh; ++y)
+            for (int x = 0; x < sw; ++x) gn[q * sps + (size_t)y * spitch + x] = probe ? 0.0f : rnd();
+    for (size_t q = 0; q < 3; ++q)
+        for (int y = 0; y < sh; ++y)
+            for (int x = 0; x < spitch; ++x) en[q * sps + (size_t)y * spitch + x] = probe ? (x == 0 ? 5.0f : -0.0f) : (x < sw ? rnd() : 0.f);
+    const size_t bytes[] = {g.size() * 4, gn.size() * 4, en.size() * 4, 3 * ps * 4, 3 * ps * 4, (size_t)w * 4, (size_t)w * 8, (size_t)h * 4, (size_t)h * 8};
+    size_t off[10] = {0};
+    for (int i = 0; i < 9; ++i) off[i + 1] = off[i] + align256(bytes[i]);
+    char* base = nullptr;
+    HIPCHK(hipMalloc((void**)&base, off[9] + 256));
+    auto up = [&](int i, const void* src) { return hipMemcpy(base + off[i], src, bytes[i], hipMemcpyHostToDevice) == hipSuccess; };
+    bool ok = up(0, g.data()) && up(1, gn.data()) && up(2, en.data()) && up(5, ix.data()) && up(6, ax.data()) && up(7, iy.data()) && up(8, ay.data()) &&
+              hipMemset(base + off[3], 0xff, 2 * align256(bytes[3])) == hipSuccess;
+    std::vector<float> o1(3 * ps), o2(3 * ps);
+    if (ok) {
+        const ExpandTab tb{(const int32_t*)(base + off[5]), (const double*)(base + off[6]), (const int32_t*)(base + off[7]), (const double*)(base + off[8])};
+        const int crows = 8, strips = (h + crows - 1) / crows;
+        for (int v = 0; v < 2; ++v) {  // v = 0: k_collapse4 with per-lane taps on [0, gxb), one column per work-item behind; v = 1: k_collapse everywhere
+            OutPtrs<float> eo{};
+            eo.p[0] = (float*)(base + off[3 + v]);
+            CollapseArgs<float, false> A{(const float*)(base + off[0]), w, h, pitch, ps, (const float*)(base + off[1]), (const float*)(base + off[2]), sw, sh, spitch, sps,
+                                         tb, eo, pitch, ps, nullptr, NoPairArgs{}, 0, crows, 0, v == 0 ? gxb : 0, 1, 0, 1};
+            if (v == 0) {
+                const int rest = pitch - gxb, nb4 = (gxb / 4 + WAVE - 1) / WAVE, ncb = (rest + C4_THREADS - 1) / C4_THREADS;
+                k_collapse4<float, false, false, true><<<dim3(c4_padded_blocks(nb4, A.swizzle) + ncb * C4_SUB, strips, 1), C4_THREADS>>>(A, nb4, ncb);
+            } else
+                k_collapse<float, false><<<grid_xy(pitch, strips, 1), 256>>>(A);
+        }
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(o1.data(), base + off[3], bytes[3], hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(o2.data(), base + off[4], bytes[4], hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    const hipError_t e = ok ? hipSuccess : hipGetLastError();
+    (void)hipFree(base);
+    if (!ok) return fail(STITCH_ERR_HIP, "check_collapse_taps: %s", hipGetErrorString(e));
+    unsigned long long n = 0, bad = 0;
+    for (size_t q = 0; q < 3; ++q)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x, ++n) {
+                uint32_t a, b;
+                std::memcpy(&a, &o1[q * ps + (size_t)y * pitch + x], 4);
+                std::memcpy(&b, &o2[q * ps + (size_t)y * pitch + x], 4);
+                bad += a != b;
+            }
+    *compared = n;
+    *mismatches = bad;
+    return STITCH_OK;
+}
 int stitch_dev_quantize_u8(const float* d_src, uint8_t* d_dst, size_t n, void* stream) {
     int rc = need_device();
     if (rc) return rc;

@@ -454,6 +454,13 @@ int stitch_dev_quantize_u8(const float *d_src, uint8_t *d_dst, size_t n, void *s
  * float bit pattern inside the range (about 2^31.4 numerators, a fraction of a second) for one denominator w (an integer value,
  * 2 <= w < 2^24) and returns the number of numerators tested and the number of quotients that differ -- which must be 0. */
 int stitch_dev_check_fastdiv(float w, unsigned long long *tested, unsigned long long *mismatches);
+/* Verification hook.  One collapse level (CImg.h:29618-29690 + ImageProcess.cpp:756-770) of w x h samples on synthetic planes, run twice:
+ * by k_collapse4 with per-lane tap offsets over whole rows -- the form every plan takes -- and by k_collapse, which forms every tap pair
+ * (ix, min(ix + 1, sw - 1)) the way the reference does; the two results are compared bit for bit.  probe 0: pseudo-random finite samples of
+ * both signs; probe 1: planes of signed zeros built so that a column whose first tap is the source row's last sample comes out -0.0f only
+ * if that sample is taken twice (CImg.h:29648) and +0.0f if the sample behind it in the 16-byte window (the next row's first) were used.
+ * w, h even, 256 <= w, 4 <= h, both <= 16384.  Returns the samples compared and the number that differ -- which must be 0. */
+int stitch_dev_check_collapse_taps(int w, int h, int probe, unsigned long long *compared, unsigned long long *mismatches);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,35 @@ def test_blend_f32(st, gpu, oracle, w, h):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"f32 not bit-equal, max err {err}"
 
 
+@pytest.mark.parametrize("w", [256, 512, 768, 1024, 1280, 1536, 2048, 3072])
+def test_collapse_row_end_tap_even_widths(st, gpu, oracle, w):
+    """k_collapse4 covers whole rows of every even-width level with per-lane tap offsets (round 4): the first group of a row has the
+    taps 0, 0, 0, 1, the last one ends on the source row's last sample, whose second tap is that sample again (CImg.h:29648) although the
+    16-byte window behind it reaches into the next row.  Widths whose levels are multiples of 256, float canvases bit for bit (a wrong
+    second tap under alpha = 0 shows only as the sign of a zero), with a black band so that exact zeros of both signs occur."""
+    h = w // 2 + 2  # (the shorter side must reach the pyramid's top: ImageProcess.cpp:675-684)
+    A, B = two_canvases(oracle, w, h, 11, 12, np.float32)
+    A[:, 8:20, :] = 0.0  # (away from the middle row, which the seam scan needs)
+    B[:, h - 26:h - 12, w // 2:] = 0.0
+    rc, ref, rs = oracle.blend(A, B)
+    assert rc == 0
+    got, s = st.blend(A, B)
+    assert s.as_tuple() == rs.as_tuple()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"{(got.view(np.uint32) != ref.view(np.uint32)).sum()} samples differ"
+
+
+@pytest.mark.parametrize("w", [256, 512, 1024, 1280, 1536, 2048, 3072, 6144, 1030, 4422])
+@pytest.mark.parametrize("probe", [0, 1])
+def test_collapse_per_lane_taps_equal_the_reference_taps(st, gpu, w, probe):
+    """One collapse level on synthetic planes by k_collapse4 (per-lane tap offsets over whole rows, the form every plan takes) and by
+    k_collapse (every tap pair formed as CImg.h:29648 forms it), bit for bit.  probe 1 is built so that a column whose first tap is the
+    source row's last sample comes out -0.0f only if that sample is taken twice: a build that takes the sample behind it in the window
+    instead (-DSTITCH_C4_NO_ENDTAP) fails it at every width whose last tap is clamped (256, 1024, 1280, 1536, 2048, 3072: 3 x 72 samples each, verified)."""
+    compared, bad = st.capi.dev_check_collapse_taps(w, 72, probe)
+    assert compared == 3 * w * 72
+    assert bad == 0
+
+
 def test_blend_black_regions_denormals(st, gpu, oracle):
     """Large empty areas make the recursive filter decay through the float denormal range."""
     w, h = 1500, 600
