@@ -217,7 +217,7 @@ int pyramid_levels(int w, int h, int level_rule, int* lw, int* lh) {
 // the new setting, never a stale one.  All fields are ints (no padding: compared with memcmp); -1 = not set.
 struct Tuning {
     int wavefront, no_fuse, no_src_fuse, no_zero_tiles, crows_l0, crows_ln, collapse4, xbyf_wgs, xbyf_spin_limit, xbyf_early, y2,
-        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, c4_lock, c4_swz, mover, src_lone, dec7, xbym, xbym_mpix, coarse_lds, pitch_pad;
+        recompute, stamp, gate64, coarse, single_fast, odd_dec, c4_gen, collapse_px, y1s, c4_lock, c4_swz, mover, src_lone, dec7, xbym, xbym_mpix, coarse_lds, pitch_pad, crows_wgs;
     static int env_int(const char* name) {
         const char* e = std::getenv(name);
         return e ? std::max(0, atoi(e)) : -1;
@@ -253,6 +253,7 @@ struct Tuning {
         t.xbym_mpix = env_int("STITCH_XBYM_MPIX");
         t.coarse_lds = env_int("STITCH_COARSE_LDS");
         t.pitch_pad = env_int("STITCH_PITCH_PAD");
+        t.crows_wgs = env_int("STITCH_CROWS_WGS");
         return t;
     }
     bool operator==(const Tuning& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
@@ -665,17 +666,28 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
     return launch_check("reduce");
 }
 
-int crows_of(const stitch_plan* p, int l) {
+// Rows per strip of the collapse of level l in a call with n pairs.  A strip is one serial chain of rows per work-item (load -> arithmetic ->
+// store, one row after the other) and re-uses the x-interpolated source rows best when it is long: 32 rows wherever the launch has
+// workgroups enough to hide that chain behind each other -- every batch.  A launch with few workgroups lives on the chains alone: the
+// strip of a ONE-pair call is halved until the launch has STITCH_CROWS_WGS workgroups (default 8192; 0 = round 3's rule: by the level's height alone) or
+// is 4 rows high (one pair in flight, 6144 x 4096: level 0 32 -> 8 rows, levels >= 1 32 -> 4: 2.41 -> 2.33 ms; 4421 x 2315 1.30 -> 1.25;
+// the rows two strips share are read once more per halving, which a lone pair does not notice).  STITCH_CROWS_L0 / _LN pin the height.
+int crows_of(const stitch_plan* p, int l, int n) {
+    const Level& a = p->lv[l];
+    int c;
     if (l == 0) {
-        // 32-row strips re-use the x-interpolated source rows best, but a strip is one serial chain of rows and a small canvas has
-        // few strips: 1081 x 527 in 32-row strips is 85 workgroups on 256 CUs (76 us); shorter strips where the launch would not fill
-        // the chip.  STITCH_CROWS_L0 pins the height.
         if (p->tune.crows_l0 >= 0) return p->crows_l0;
-        const int h = p->lv[0].h;
-        return h >= 2048 ? p->crows_l0 : h >= 1024 ? 16 : 8;
+        c = a.h >= 2048 ? p->crows_l0 : a.h >= 1024 ? 16 : 8;
+    } else {
+        if (p->crows_ln > 0) return p->crows_ln;
+        c = std::max(4, std::min(4 * CROWS, a.h / 32));
     }
-    if (p->crows_ln > 0) return p->crows_ln;
-    return std::max(4, std::min(4 * CROWS, p->lv[l].h / 32));
+    const long want = p->tune.crows_wgs >= 0 ? p->tune.crows_wgs : 8192;
+    const long blocks = std::max(1, (a.c4_xb - a.c4_xa) / 256);
+    // (one pair per call only: a batch has other workgroups to run meanwhile, and with four 4-pair sequences in flight shorter strips
+    // measured 5 % slower, scripts/experiments/r4_run36.sh)
+    while (n == 1 && c > 4 && blocks * ((a.h + c - 1) / c) < want) c /= 2;
+    return c;
 }
 
 template <typename OUT>
@@ -709,7 +721,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
         const int nb4 = ((xb - xa) / 4 + WAVE - 1) / WAVE, ncb = (rest + C4_THREADS - 1) / C4_THREADS;
         if (l == 0) {  // level 0: the mask is the seam's step function itself (never read from memory)
             CollapseArgs<OUT, true> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, outs,
-                                      a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, crows_of(p, 0), xa, xb, u8_words,
+                                      a.w, (size_t)a.w * a.h, p->planes_in ? nullptr : p->d_seam, pa, src ? 1 : 0, crows_of(p, 0, n), xa, xb, u8_words,
                                       std::max(0, p->tune.c4_lock), p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
             const int strips = (a.h + A.crows - 1) / A.crows;
             const dim3 g4(c4_padded_blocks(nb4, A.swizzle) + ncb * C4_SUB, strips, n);
@@ -728,7 +740,7 @@ int run_collapse(stitch_plan* p, int n, const OutPtrs<OUT>& outs, hipStream_t s,
             OutPtrs<float> eo{};
             eo.p[0] = a.e;
             CollapseArgs<float, false> A{a.g, a.w, a.h, a.pitch, a.ps, nx.g, nx.e, nx.w, nx.h, nx.pitch, nx.ps, {a.ix, a.ax, a.iy, a.ay}, eo,
-                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l), xa, xb, 1, std::max(0, p->tune.c4_lock), p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
+                                         a.pitch, a.ps, nullptr, NoPairArgs{}, 0, crows_of(p, l, n), xa, xb, 1, std::max(0, p->tune.c4_lock), p->tune.c4_swz < 0 ? 1 : p->tune.c4_swz};
             const int strips = (a.h + A.crows - 1) / A.crows;
             const dim3 g4(c4_padded_blocks(nb4, A.swizzle) + ncb * C4_SUB, strips, n);
             if (xb > xa && a.c4_gen && p->collapse4)

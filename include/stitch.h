@@ -193,6 +193,8 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *   STITCH_NO_ZERO_TILES=1    store and re-read all-zero tiles of the blur scratch like any other tile
  *   STITCH_CROWS_L0=<n>       rows per work-item strip of the level-0 collapse (default 32)
  *   STITCH_CROWS_LN=<n>       the same for the levels above (default: per level, h/32 clamped to 4..32)
+ *   STITCH_CROWS_WGS=<n>      one pair per call: the strips of the collapse are halved (down to 4 rows) until a launch has n workgroups
+ *                             (default 8192; 0 = heights by the level's size alone, as in a batch)
  *   STITCH_COLLAPSE4=0        collapse with one column and three channels per work-item everywhere (k_collapse) instead of
  *                             four columns of one channel where the resize taps are regular (k_collapse4)
  *   STITCH_XBYF_WGS=<n>       persistent workgroups of the fused sweep (default 2304)
