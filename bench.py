@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the output comparison (status() checks stay)")
     ap.add_argument("--no-coalesce", action="store_true", help="one launch sequence per step even when a rank's share of a step is "
                     "smaller than --batch (default: consecutive steps' shares are launched together, up to --batch pairs)")
+    ap.add_argument("--stagger-ms", type=float, default=0.0, help="delay (host sleep) in front of the first launch sequence of lanes 1, 2, ... "
+                    "of every timed region, inside the region: the lanes then run out of phase (A/B switch, see DESIGN.md 5)")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -267,9 +269,15 @@ def main():
         sequence running on alone at the end (20 steps, G = 4, 4 lanes: 3+3+3+3+2+2+2+2, not 4+4+4+4+4)."""
         sizes = pipeline.sequence_sizes(count, G, S)
         k = k0
+        launched = 0
         for i, g in enumerate(sizes):
             steps_ = list(range(k, k + g))
-            evs = [run_seq((k0 // G + i) * nb + j, seqs[j], steps_ if with_gather else None, copies=g) for j in range(nb)]
+            evs = []
+            for j in range(nb):
+                if args.stagger_ms > 0 and 0 < launched < S:  # the first sequence of lanes 1 .. S-1
+                    time.sleep(args.stagger_ms / 1e3)
+                launched += 1
+                evs.append(run_seq((k0 // G + i) * nb + j, seqs[j], steps_ if with_gather else None, copies=g))
             if with_gather:
                 with torch.cuda.stream(gstream):
                     for ev in evs:

@@ -80,6 +80,8 @@ def lib():
         L.stitch_last_error.restype = C.c_char_p
         L.stitch_plan_workspace_bytes.restype = C.c_size_t
         L.stitch_plan_workspace_bytes.argtypes = [C.c_void_p]
+        L.stitch_plan_workspace_base.restype = C.c_void_p
+        L.stitch_plan_workspace_base.argtypes = [C.c_void_p]
         L.stitch_plan_fast_paths.argtypes = [C.c_void_p]
         L.stitch_plan_call_forms.argtypes = [C.c_void_p, C.c_int]
         L.stitch_plan_coarse_from.argtypes = [C.c_void_p]
@@ -507,6 +509,10 @@ class Plan:
     @property
     def workspace_bytes(self):
         return lib().stitch_plan_workspace_bytes(self._h)
+
+    @property
+    def workspace_base(self):
+        return lib().stitch_plan_workspace_base(self._h) or 0
 
     def close(self):
         if self._h:

@@ -763,7 +763,9 @@ int run_seam_mask(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, 
         StageTimer t(p, s, STITCH_K_SEAM, 0);
         // 256 work-items, not 1024: a 16-wavefront workgroup waits for a CU with that much room when other batches fill the chip
         // (1.7 ms per launch with four batches in flight)
-        k_seam<PX><<<n, 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam, pa, src ? 1 : 0);
+        // (one pair per call: nothing else competes for the CU, and the scan is a chain of dependent map evaluations and gathers per
+        // work-item -- 6 of them instead of 24 at 6144 columns)
+        k_seam<PX><<<n, n == 1 ? 1024 : 256, 0, s>>>(a.g, a.w, a.h, a.pitch, a.ps, p->opts.seam_rule, p->d_seam, pa, src ? 1 : 0);
     }
     if (!p->mask_opt) {
         StageTimer t(p, s, STITCH_K_MASK, 0);
@@ -1933,6 +1935,7 @@ void stitch_plan_destroy(stitch_plan* p) {
 }
 
 size_t stitch_plan_workspace_bytes(const stitch_plan* p) { return p ? p->arena_bytes : 0; }
+const void* stitch_plan_workspace_base(const stitch_plan* p) { return p ? p->arena : nullptr; }
 
 int stitch_plan_levels(const stitch_plan* p, int* level_w, int* level_h) {
     if (!p) return fail(STITCH_ERR_ARG, "null plan");

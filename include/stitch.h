@@ -148,6 +148,8 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts *opts, in
 int stitch_plan_capacity(const stitch_plan *plan);
 void stitch_plan_destroy(stitch_plan *plan);
 size_t stitch_plan_workspace_bytes(const stitch_plan *plan);
+/* Device address of the plan's workspace (diagnostics: placement experiments, scripts/experiments/exp_placement.py). */
+const void *stitch_plan_workspace_base(const stitch_plan *plan);
 int stitch_plan_levels(const stitch_plan *plan, int *level_w, int *level_h);
 /* Number of finest pyramid levels whose anticausal-x and causal-y sweeps run fused (k_vv_xbyf).  Chosen at plan
  * creation: for batched plans (max_pairs >= 2) and for single pairs at least 7360 rows high (many row bands in flight),
