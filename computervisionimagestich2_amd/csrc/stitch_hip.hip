@@ -385,6 +385,7 @@ int launch_check(const char* what) {
 
 // The fused anticausal-x + causal-y sweep of a call with n pairs (see run_reduce): a per-CALL choice, like src_fused_call.
 bool fused_sweep_call(const stitch_plan* p, int n) {
+    if (n == 1 && p->tune.xbym == 2) return false;  // A/B: one pair of ANY size takes the five-wavefront form (k_vv_xby_m) where it applies
     return p->tune.wavefront >= 0 || p->tune.single_fast > 0 || n >= 2 || 7L * ((p->lv[0].h + TS - 1) / TS) >= 800;
 }
 
