@@ -302,6 +302,7 @@ struct stitch_plan {
     uint8_t* zi = nullptr;         // [cap][tiles][bands] of level 0: "every pixel of the tile lies outside the frame" (k_src_index)
     uint8_t* zt = nullptr;         // zero-tile flags of T, [7*cap][bands][tiles] of level 0 (ZeroTiles); reused level by level
     bool zero_tiles = false;
+    const float* zero_page = nullptr;  // 4 KB of zeros in the arena (k_vv_xby_m's loader reads a flagged tile from here)
     int wf_max_wgs = 2304;  // persistent workgroups of the fused sweep (STITCH_XBYF_WGS)
     unsigned wf_spin_limit = 1u << 23;  // polls before a hand-off wait gives up, about 20 s (STITCH_XBYF_SPIN_LIMIT); 2^20 (2-3 s) was reached once in a warm-up
     int wf_early_read = 1;  // STITCH_XBYF_EARLY=0: poll for the hand-off only when it is needed
@@ -384,9 +385,10 @@ int launch_check(const char* what) {
 }
 
 // The fused anticausal-x + causal-y sweep of a call with n pairs (see run_reduce): a per-CALL choice, like src_fused_call.
+// (Until round 4 one pair of >= 800 bands -- config 5 -- took the batch's sweep too; the five-wavefront form with zero-tile flags is 2.6 %
+// faster there, 22.3 against 22.9 ms per pair.  STITCH_XBYM=0 brings the old choice back.)
 bool fused_sweep_call(const stitch_plan* p, int n) {
-    if (n == 1 && p->tune.xbym == 2) return false;  // A/B: one pair of ANY size takes the five-wavefront form (k_vv_xby_m) where it applies
-    return p->tune.wavefront >= 0 || p->tune.single_fast > 0 || n >= 2 || 7L * ((p->lv[0].h + TS - 1) / TS) >= 800;
+    return p->tune.wavefront >= 0 || p->tune.single_fast > 0 || n >= 2 || (p->tune.xbym == 0 && 7L * ((p->lv[0].h + TS - 1) / TS) >= 800);
 }
 
 // One pair in flight: the anticausal x and the causal y sweep of level l as ONE launch of five-wavefront bands (k_vv_xby_m) where the
@@ -429,7 +431,12 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
         // zero-tile flags: only where all three users run (causal x sweep, fused sweep, fused anticausal-y + decimation)
         const int NR = (a.h + TS - 1) / TS;  // 64-row bands per plane, the last one possibly partial
         ZeroTiles zt{};
-        if (wavefront && p->zero_tiles && NR <= 256 && ((a.w & 1) == 0 || odd_dec) && !p->no_fuse && !(p->tune.gate64 && (a.h % TS || (a.w & 1)))) {
+        // (the five-wavefront sweep of ONE pair carries the flags too where its x sweeps are the one-wavefront kernels anyway -- more bands
+        // than the chain + loader + storer form takes: a pair of config 5's size)
+        const int nbx_bands = np * NR;
+        const bool xby_zt = !wavefront && p->zt && do_x && do_y && lone_fused_level(p, n, l) && (a.w + TS - 1) / TS <= XY_MAXNC &&
+                            !(p->tune.mover != 0 && (nbx_bands <= 340 || (src && l == 0 && nbx_bands <= 1024)));
+        if ((wavefront || xby_zt) && p->zero_tiles && NR <= 256 && ((a.w & 1) == 0 || odd_dec) && !p->no_fuse && !(p->tune.gate64 && (a.h % TS || (a.w & 1)))) {
             zt.flags = p->zt;
             zt.h = a.h;
             zt.NR = NR;
@@ -561,6 +568,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 wf.NP = np;
                 wf.epoch = 1;
                 wf.mask_l0 = mk.enabled;
+                wf.zt = zt;
                 if (p->xy_dbg && l == 0) wf.dbg = p->xy_dbg, p->xy_dbg_nc = wf.NC;
                 // every polled word is cleared in front of the launch (see the batch form above)
                 const size_t gran_words = (size_t)wf.NP * wf.NC * WF_GRAN * WAVE;
@@ -570,7 +578,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 ystate = state_y;
                 StageTimer t(p, s, STITCH_K_VV_XBYF, l);
                 // two workgroups per CU by LDS: every band of a lone 6144 x 4096 pair (448) is resident at once
-                k_vv_xby_m<<<(int)std::min<long>((long)wf.NP * wf.NR, 512), XY_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf);
+                k_vv_xby_m<<<(int)std::min<long>((long)wf.NP * wf.NR, 512), XY_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf, p->zero_page);
             }
             if (do_y) {
                 dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
@@ -594,8 +602,22 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 StageTimer t(p, s, STITCH_K_VV_Y_BWD, l);
                 // loader + two chains + four consumers, free-running (k_vv_y_bwd_dec7) where the launch leaves SIMDs idle; the two-wavefront
                 // kernel otherwise
-                const bool dec7 = lone && small_plane && p->tune.dec7 != 0;
-                if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
+                const bool dec7 = lone && small_plane && p->tune.dec7 != 0 && !zt.flags;
+                if (zt.flags && ((a.w & 1) == 0 || odd_dec) && !p->no_fuse) {  // (zero-tile flags from k_vv_xby_m: the kernels that read them)
+                    if ((a.w & 1) == 0) {
+                        if (rowz)
+                            k_vv_y_bwd_dec<true><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
+                        else
+                            k_vv_y_bwd_dec<false><<<g, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
+                    } else {
+                        const dim3 go((b.w + WAVE - 2) / (WAVE - 1), np);
+                        if (rowz)
+                            k_vv_y_bwd_dec<true, YST, true, true><<<go, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
+                        else
+                            k_vv_y_bwd_dec<false, YST, true, true><<<go, 128, 0, s>>>(p->T, a.w, a.h, a.pitch, a.ps, p->vvk, ystate, b.g, b.w, b.h, b.pitch, b.ps, zt, nullptr, nullptr, a.h, b.h);
+                    }
+                    decimated = true;
+                } else if ((a.w & 1) == 0 && !p->no_fuse) {  // even width: decimation fused into the anticausal pass
                     if (dec7) {
                         unsigned long long* dbg = p->d7_dbg && l == p->d7_dbg_level ? p->d7_dbg : nullptr;
                         if (dbg) p->d7_dbg_chunks = (a.h + YCH - 1) / YCH;
@@ -1716,6 +1738,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
     const size_t st_off = take(sizeof(double) * state_n);
     const size_t seam_off = take(sizeof(SeamDev) * B);
     const size_t side_off = take(sizeof(float) * B * v0.pitch);
+    const size_t zp_off = take(4096);  // zeros for good (k_vv_xby_m's loader reads a flagged tile from here)
     p->arena_bytes = off;
     if (hipMalloc(&p->arena, off) != hipSuccess) {
         (void)hipGetLastError();
@@ -1776,6 +1799,7 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         p->zero_tiles = !tn.no_zero_tiles;  // A/B and tests: move the zeros like any other sample
     }
     p->side = reinterpret_cast<float*>(base + side_off);
+    p->zero_page = reinterpret_cast<const float*>(base + zp_off);
     // implicit level-0 mask: needs both Van Vliet sweeps at level 0 (the x sweeps then run per-plane bands, Bands, at any height;
     // STITCH_GATE64=1 restores the old restriction to heights that are multiples of 64 for A/B runs)
     p->mask_opt = !p->no_fuse && o.blur_kind == 0 && !p->blur_skip && L >= 2 && v0.w > 1 && v0.h > 1 && !(tn.gate64 && v0.h % 64);
@@ -1807,6 +1831,9 @@ int stitch_plan_create_batched(int cw, int ch, const stitch_blend_opts* opts, in
         stitch_plan_destroy(p);
         return fail(STITCH_ERR_HIP, "plan_create: workspace initialisation failed");
     }
+#ifdef STITCH_ZP_POISON  // (defined only to prove that a test reads flagged tiles from here: the page is then anything but zero)
+    (void)hipMemset(base + zp_off, 0x3f, 4096);
+#endif
     // resize tables (CImg.h:29625-29637), computed on the host once per plan
     for (int l = 0; l + 1 < L; ++l) {
         Level& v = p->lv[l];

@@ -231,10 +231,10 @@ int stitch_plan_coarse_from(const stitch_plan *plan);
  *                             its own run of adjacent strips top to bottom (the rows two strips share meet in one L2 too)
  *   STITCH_PITCH_PAD=<n>      floats added to the row pitch of levels of 4096 columns and more (A/B: measured no effect, default 0)
  *   STITCH_D7_STAMP=<level>   diagnostics: per-chunk time stamps of the seven wavefronts of one workgroup of k_vv_y_bwd_dec7 at that level
- *   STITCH_XBYM=0|1|2         one pair in flight: anticausal x + causal y sweep of a level as ONE launch of five-wavefront bands
- *                             (k_vv_xby_m): 0 = never, 1 = at the first four levels whatever their size (tests), 2 = as 1 and also for a pair so
- *                             large that it would take the batch's fused sweep (config 5: 4.84 against 5.35 ms at level 0, but no zero-tile
- *                             flags on that path: 23.0 against 22.9 ms per pair, no gain); default: where the
+ *   STITCH_XBYM=0|1           one pair in flight: anticausal x + causal y sweep of a level as ONE launch of five-wavefront bands
+ *                             (k_vv_xby_m; with zero-tile flags where the plan owns them and the level has more bands than the chain + loader +
+ *                             storer sweeps take): 0 = never (a pair of >= 800 bands then runs the batch's fused sweep, as until round 4),
+ *                             1 = at the first four levels whatever their size (tests); default: where the
  *                             separate sweeps are bound by their bytes, from STITCH_XBYM_MPIX megapixels per plane (default 20)
  *   STITCH_XBYM_STAMP=1       diagnostics: per-tile time stamps of the five wavefronts of one band of k_vv_xby_m, printed at plan destruction
  *   STITCH_COARSE_LDS=0       coarse levels in global memory (k_coarse) instead of LDS (k_coarse_lds, where the levels fit into 144 KB)

@@ -652,6 +652,31 @@ def test_dev_blend_into_one_of_its_inputs(st, gpu, oracle, dtype, monkeypatch):
     plan.close()
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_lone_fused_sweep_with_zero_tile_flags(st, gpu, oracle, dtype, monkeypatch):
+    """k_vv_xby_m with zero-tile flags (a plan that owns flags -- here a batched one -- asked for ONE pair under STITCH_XBYM=1, at a
+    size where a level has more bands than the chain + loader + storer sweeps take: > 1024 at the source-fused level 0, > 340 above):
+    the loader reads flagged tiles from the plan's zero page, the storer records full all-zero tiles instead of storing them, the
+    anticausal y sweep + decimation reads the flags.  A tall narrow canvas (148 / 74 bands per plane at levels 0 / 1; partial last
+    band and tile) whose frame covers a third of it, so that most tiles of three planes are zero; against the oracle bit for bit."""
+    import torch
+    from computervisionimagestich2_amd import capi
+    monkeypatch.setenv("STITCH_XBYM", "1")
+    cw, ch, fw, fh = 1100, 9450, 420, 9000
+    F, M = oracle.synth(fw, fh, 21, dtype), oracle.synth(cw - 300, ch - 5, 22, dtype)
+    P = [1.0, 0.002, 1e-6, -(cw - fw - 3.0), -0.001, 1.0, 5e-7, -3.5]
+    opts = dict(sigma=2.0, blur_kind=0, level_rule=1, seam_rule=0)  # levels from the SHORTER side (the canvas is nine times as tall as wide)
+    rc, ref = oracle.pair(F, P, -0.25, -1.5, M, 0, -2, cw, ch, opts=opts)
+    assert rc == 0, rc
+    plan = capi.Plan(cw, ch, opts=opts, max_pairs=2)
+    assert plan.fused_sweep_levels >= 1 and "fused_sweep" in plan.call_forms(1)
+    out = torch.empty((3, ch, cw), dtype=torch.from_numpy(F).dtype, device=gpu)
+    plan.pairs([(torch.from_numpy(F).to(gpu), P, -0.25, -1.5, torch.from_numpy(M).to(gpu), 0, -2, out)])
+    plan.status(0)
+    assert np.array_equal(out.cpu().numpy().view(np.uint8), ref.view(np.uint8))
+    plan.close()
+
+
 @pytest.mark.parametrize("lds", ["0", None])
 def test_coarse_levels_in_lds_and_in_global_memory_agree(st, gpu, oracle, lds, monkeypatch):
     """The coarse levels of a pyramid run in one launch per pair: k_coarse_lds (every level in LDS, the default where they fit) or
