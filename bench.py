@@ -463,8 +463,15 @@ def main():
         # the forms the timed launch sequences ran with, from the plan and the library's per-call rule (not re-derived from the environment)
         forms = plan.call_forms(n_seq0)
         src_fused = "source_fused" in forms
-        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, px_bytes,
-                                                        plan.fused_sweep_levels if "fused_sweep" in forms else 0,
+        # levels whose anticausal-x and causal-y sweeps are one launch: the plan's (a batch), or -- one pair per sequence, the
+        # five-wavefront sweep -- the first levels of 20 MPix and more (the library's rule, lone_fused_level)
+        if "fused_sweep" not in forms:
+            fused_levels = 0
+        elif n_seq0 == 1:
+            fused_levels = sum(1 for l_ in range(min(4, len(plan.level_w) - 1)) if plan.level_w[l_] * plan.level_h[l_] >= 20_000_000)
+        else:
+            fused_levels = plan.fused_sweep_levels
+        per_kernel, stages = pipeline.algorithmic_bytes(F * F, F * F, plan.level_w, plan.level_h, px_bytes, fused_levels,
                                                         fused_decimate="fused_decimate" in plan.fast_paths, source_fused=src_fused,
                                                         implicit_mask="implicit_mask" in plan.fast_paths, coarse_from=plan.coarse_from)
         line = {
@@ -479,7 +486,7 @@ def main():
                                    + (f" (the shares of {G} consecutive steps launched together: {B * G} pairs per sequence)" if G > 1 else "") + " on batched plans, "
                                    f"{S} sequences in flight per GPU on separate HIP streams; canvas pixels counted",
                        "frame": [F, F, 3], "canvas": [cw, ch, 3], "levels": plan.levels, "pairs_per_step": P, "pairs_per_rank_per_step": n_local,
-                       "pairs_per_sequence": B * G, "steps_per_sequence": G, "sequences_in_flight": S, "fused_sweep_levels": plan.fused_sweep_levels,
+                       "pairs_per_sequence": B * G, "steps_per_sequence": G, "sequences_in_flight": S, "fused_sweep_levels": fused_levels,
                        "forms": sorted(forms), "backend": ("gloo REHEARSAL on one GPU: not a scaling measurement" if rehearsal else "nccl (RCCL)") if use_dist else None,
                        "per_rank": [{"rank": r_, "pairs_per_step": v[0], "sequences_per_step": v[1], "steps_per_sequence": v[2], "lanes": v[3],
                                      "gather_input_blocks": (v[3] + 1) * v[2] if use_gather else 0} for r_, v in enumerate(per_rank)],
@@ -530,7 +537,10 @@ def main():
             torch.cuda.synchronize()
             copy_gbs = 5 * 2 * csrc.numel() / (c0.elapsed_time(c1) / 1e3) / 1e9
             del csrc, cdst
-            line["roofline"] = {"bound": "hbm", "kernel": capi.KERNEL_SYMBOLS[dom].replace("<T,", "<float,"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            dom_sym = capi.KERNEL_SYMBOLS[dom].replace("<T,", "<float,")
+            if dom == "vv_xbyf" and n_seq0 == 1:  # one pair per sequence: the five-wavefront sweep, not the batch's
+                dom_sym = "k_vv_xby_m"
+            line["roofline"] = {"bound": "hbm", "kernel": dom_sym, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                                 "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command run by the builder "
                                                   "(scripts/pmc.sh); NOT measured in this run" if traffic is not None else None,
