@@ -578,7 +578,7 @@ int run_reduce(stitch_plan* p, int n, hipStream_t s, const PairArgs<PX>& pa, boo
                 ystate = state_y;
                 StageTimer t(p, s, STITCH_K_VV_XBYF, l);
                 // two workgroups per CU by LDS: every band of a lone 6144 x 4096 pair (448) is resident at once
-                k_vv_xby_m<<<(int)std::min<long>((long)wf.NP * wf.NR, 512), XY_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf, p->zero_page);
+                k_vv_xby_m<<<(int)std::min<long>((long)wf.NP * wf.NR, XY_WGS), XY_THREADS, 0, s>>>(p->T, a.w, a.h, a.pitch, p->vvk, p->state, lines, state_y, wf, p->zero_page);
             }
             if (do_y) {
                 dim3 g((a.pitch + YCOLS - 1) / YCOLS, np);
