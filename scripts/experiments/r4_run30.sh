@@ -6,7 +6,7 @@ for i in $(seq 1 ${SOAK_N:-40}); do
   t0=$(date +%s.%N)
   timeout -k 10 180 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-single > $O/b_$i.json 2> $O/b_$i.err; rc=$?
   t1=$(date +%s.%N)
-  python - $O/b_$i.json $i $rc $(echo "$t1 - $t0" | bc) <<'PY'
+  python - $O/b_$i.json $i $rc 0 <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']
