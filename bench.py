@@ -569,14 +569,14 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_frame, args.verbose)
             # the reference's OWN loop on the same pair (unsigned char frames, one thread: ~2 minutes, so not inside this run):
             # timed once on a GPU box's host by scripts/bench_reference_config2.py, which also compares the MI355X result with it
-            rpath = os.path.join(ROOT, "profiles", "r03_reference_config2.json")
+            rpath = os.path.join(ROOT, "profiles", "r04_reference_config2.json")
             if os.path.exists(rpath) and F == 4096:
                 try:
                     rj = json.load(open(rpath))
                     line["cpu_baseline_reference"] = {"value": rj["value"], "unit": rj["unit"], "cores": rj["cores"], "kind": "reference", "measured_offline": True,
                                                       "sample": f"the reference's warpingImageByHomography + movingImageByOffset + blendTwoImages ({rj['reference_lines']}) "
                                                                 f"compiled in place, config 2's pair with unsigned char frames, {rj['total_s']} s on one thread of a GPU box's "
-                                                                "host (profiles/r03_reference_config2.json, scripts/bench_reference_config2.py)",
+                                                                "host (profiles/r04_reference_config2.json, scripts/bench_reference_config2.py)",
                                                       "mi355x_bit_identical": rj.get("mi355x_same_pair", {}).get("bit_identical_to_the_reference")}
                 except Exception:
                     pass

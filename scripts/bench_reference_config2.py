@@ -3,7 +3,7 @@ reference CImg CPU loop timed on the same box's host cores"): warpingImageByHomo
 blendTwoImages (ImageProcess.cpp:596-620,648-773) from oracle/_ref/libref_hotpath.so -- the reference's sources compiled in
 place by oracle/Makefile -- on two 4096x4096x3 unsigned char frames (the reference's pixel type) -> 6144x4096 canvas,
 ONE thread (the reference is single-threaded on this path).  The MI355X result of the same pair is compared with it byte
-for byte.  ~2-3 minutes of CPU.  Usage: python scripts/bench_reference_config2.py > profiles/r03_reference_config2.json"""
+for byte.  ~2-3 minutes of CPU.  Usage: python scripts/bench_reference_config2.py > profiles/r04_reference_config2.json"""
 import hashlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
