@@ -80,6 +80,7 @@ def lib():
         L.stitch_last_error.restype = C.c_char_p
         L.stitch_plan_workspace_bytes.restype = C.c_size_t
         L.stitch_plan_workspace_bytes.argtypes = [C.c_void_p]
+        L.stitch_plan_collapse_range.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.stitch_plan_workspace_base.restype = C.c_void_p
         L.stitch_plan_workspace_base.argtypes = [C.c_void_p]
         L.stitch_plan_fast_paths.argtypes = [C.c_void_p]
@@ -509,6 +510,12 @@ class Plan:
     @property
     def workspace_bytes(self):
         return lib().stitch_plan_workspace_bytes(self._h)
+
+    def collapse_range(self, level):
+        """stitch_plan_collapse_range: (xa, xb, per_lane_taps) of the collapse of `level`."""
+        xa, xb, g = C.c_int(), C.c_int(), C.c_int()
+        _chk(lib().stitch_plan_collapse_range(self._h, int(level), C.byref(xa), C.byref(xb), C.byref(g)))
+        return xa.value, xb.value, g.value
 
     @property
     def workspace_base(self):

@@ -2044,6 +2044,14 @@ int stitch_plan_fast_paths(const stitch_plan* p) {
     return f;
 }
 int stitch_plan_fused_sweep_levels(const stitch_plan* p) { return p ? p->wf_levels : 0; }
+int stitch_plan_collapse_range(const stitch_plan* p, int level, int* xa, int* xb, int* per_lane_taps) {
+    if (!p || level < 0 || level + 1 >= p->L || !xa || !xb || !per_lane_taps) return fail(STITCH_ERR_ARG, "plan_collapse_range: bad argument");
+    const Level& v = p->lv[level];
+    *xa = p->collapse4 ? v.c4_xa : 0;
+    *xb = p->collapse4 ? v.c4_xb : 0;
+    *per_lane_taps = p->collapse4 ? v.c4_gen : 0;
+    return STITCH_OK;
+}
 int stitch_plan_call_forms(const stitch_plan* p, int n_pairs) {
     if (!p || n_pairs < 1 || n_pairs > p->cap) return 0;
     int f = 0;

@@ -157,6 +157,11 @@ int stitch_plan_levels(const stitch_plan *plan, int *level_w, int *level_h);
  * STITCH_WAVEFRONT=<n> levels when that environment variable is set (0 = always separate sweeps).  Results are
  * identical either way. */
 int stitch_plan_fused_sweep_levels(const stitch_plan *plan);
+/* How the collapse of `level` (0 .. levels - 2) is launched: columns [*xa, *xb) run four per work-item (k_collapse4), the rest one per
+ * work-item; *per_lane_taps != 0: with per-lane tap offsets (whole rows of an even-width level), 0: only where the fixed tap pattern holds.
+ * Introspection for tests: a level of 256 columns and more whose [*xa, *xb) does not cover its rows fell back to the one-column path,
+ * which is what the collapse over-fetched through in round 3.  STITCH_ERR_ARG for a level without a collapse. */
+int stitch_plan_collapse_range(const stitch_plan *plan, int level, int *xa, int *xb, int *per_lane_taps);
 /* Which of the forms that avoid HBM round trips this plan's level 0 runs with (a bit mask; results never depend on it):
  *   IMPLICIT_MASK   the level-0 mask (a vertical step, ImageProcess.cpp:690-698) is generated where it is needed, never stored
  *   SOURCE_FUSED    level 0 of a and b is read from the caller's frames / canvases by its consumers, never materialised

@@ -123,6 +123,23 @@ def test_collapse_per_lane_taps_equal_the_reference_taps(st, gpu, w, probe):
     assert bad == 0
 
 
+def test_collapse_covers_whole_rows(st, gpu):
+    """The four-column path of the collapse covers every 256-column block of every level wide enough for it -- the one-column path it used
+    to fall back to at the first and the last block of every even-width level is what the collapse over-fetched through in round 3 (101 MB
+    per pair at level 0).  Even widths: [0, w rounded down to 256) with per-lane taps; an odd width (4421): all but the ragged end; with
+    STITCH_C4_GEN=0 the fixed pattern leaves the first and the last block out (the A/B form)."""
+    from computervisionimagestich2_amd import capi
+    for (cw, ch) in [(6144, 4096), (2048, 1024), (4421, 2315), (1024, 512)]:
+        plan = capi.Plan(cw, ch)
+        for l in range(plan.levels - 1):
+            w = plan.level_w[l]
+            if w < 512:
+                break
+            xa, xb, gen = plan.collapse_range(l)
+            assert (xa, xb, gen) == (0, (w - (w % 4 != 0) * 4) // 256 * 256 if w % 2 else w // 256 * 256, 1), (cw, l, w, xa, xb, gen)
+        plan.close()
+
+
 def test_blend_black_regions_denormals(st, gpu, oracle):
     """Large empty areas make the recursive filter decay through the float denormal range."""
     w, h = 1500, 600
